@@ -1,0 +1,166 @@
+/*
+ * mvhip.h — C-ABI of libmvhip.so, the MI355X (gfx950 / CDNA4) kernels behind
+ * mini-vllm's paged-attention inference hot path.
+ *
+ * The reference (jianzhnie/mini-vllm) is pure Python and has no FFI; its
+ * pluggable seam is the AttentionBackend ABC and the layer classes.  Every
+ * entry point below names the reference interface it replaces (paths are
+ * relative to the reference checkout).
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, <0 for an argument error (MV_E_*), >0 = hipError_t
+ *   - no allocation, no host<->device sync, no host reads of device memory,
+ *     no global state: every launch goes to the caller's `stream`
+ *     (a hipStream_t) and is hipGraph-capturable
+ *   - pointers are device pointers (tensor.data_ptr()); strides are in ELEMENTS
+ *   - `dtype` selects the element type of activations, KV cache and weights
+ *   - index tensors: slot_mapping / block_tables / context_lens / cu_seqlens
+ *     are int32; positions, top_ks and sampled tokens are int64 (the dtypes
+ *     the reference engine produces, engine/inference_executor.py:520-549,
+ *     :149-180, :787-796)
+ */
+#ifndef MVHIP_H
+#define MVHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MV_ABI_VERSION 1
+
+typedef enum { MV_BF16 = 0, MV_F16 = 1, MV_F32 = 2 } mv_dtype;
+
+enum {
+  MV_OK = 0,
+  MV_E_NULLPTR = -1,   /* a required pointer is NULL                       */
+  MV_E_SHAPE = -2,     /* unsupported / inconsistent shape                 */
+  MV_E_DTYPE = -3,     /* unknown dtype                                    */
+  MV_E_WORKSPACE = -4, /* workspace too small                              */
+  MV_E_ALIGN = -5,     /* pointer or stride not aligned for 16-byte access */
+  MV_E_RANGE = -6      /* scalar argument out of range                     */
+};
+
+int mv_version(void);
+const char *mv_strerror(int code);
+
+/* K1 — scatter new K/V rows into the paged cache.
+ * Replaces StandardAttentionBackend.store_kv_cache and the Triton
+ * store_kvcache_kernel (minivllm/models/layers/attention_backend.py:50-78,
+ * :196-266).  k,v: [n_tok, n_kv_heads, head_dim] with token stride
+ * k_stride_tok / v_stride_tok (views of the fused qkv GEMM output);
+ * caches: contiguous [num_slots, n_kv_heads*head_dim] (= [nb, bs, Hkv, D]).
+ * Rows with slot < 0 are skipped (reference :70-71); rows with
+ * slot >= num_slots are skipped too (the reference would fault). */
+int mv_store_kvcache(const void *k, const void *v, int64_t k_stride_tok,
+                     int64_t v_stride_tok, void *k_cache, void *v_cache,
+                     const int32_t *slot_mapping, int n_tok, int n_kv_heads,
+                     int head_dim, int64_t num_slots, int dtype, void *stream);
+
+/* K6 — RMSNorm.  Replaces RMSNorm.rms_forward
+ * (minivllm/models/layers/layernorm.py:81-93): fp32 math,
+ * y = ((x * rsqrt(mean(x^2)+eps)) * w) -> dtype. */
+int mv_rmsnorm(const void *x, int64_t x_stride, const void *w, void *out,
+               int64_t out_stride, int rows, int cols, float eps, int dtype,
+               void *stream);
+
+/* K6 — fused residual-add + RMSNorm.  Replaces RMSNorm.add_rms_forward
+ * (layernorm.py:95-105): s = f32(x)+f32(residual); residual <- s -> dtype
+ * (in place); out = norm(s) from the UNROUNDED sum. */
+int mv_add_rmsnorm(const void *x, int64_t x_stride, void *residual,
+                   int64_t res_stride, const void *w, void *out,
+                   int64_t out_stride, int rows, int cols, float eps,
+                   int dtype, void *stream);
+
+/* K7 (+K6 per-head, +K1) — q/k head RMSNorm (optional) -> NeoX RoPE -> K/V
+ * cache store, one launch.  Replaces q_norm/k_norm + RotaryEmbedding.forward
+ * + store_kv_cache on the flat path (minivllm/models/qwen_base.py:173-190,
+ * layers/rotary_embedding.py:77-81,166-193, attention_backend.py:196-266).
+ * q: [n_tok,H,D] stride q_stride_tok; k,v: [n_tok,Hkv,D]; positions int64;
+ * cos,sin: fp32 [max_pos, D/2].  q_norm_w/k_norm_w (dtype, [D]) may both be
+ * NULL (Qwen2).  q_out [n_tok,H,D] contiguous is required; k_out
+ * [n_tok,Hkv,D] contiguous may be NULL (decode); k_cache/v_cache/slot_mapping
+ * may all be NULL (warm-up prefill has no slots, inference_executor.py:373-410).
+ * Rounding points follow the reference: norm -> dtype, then rope in fp32 ->
+ * dtype.  positions outside [0,max_pos) give MV-defined zeros rotation
+ * (cos=1,sin=0) instead of the reference's index error. */
+int mv_rope_qk_store(const void *q, const void *k, const void *v,
+                     int64_t q_stride_tok, int64_t k_stride_tok,
+                     int64_t v_stride_tok, const int64_t *positions,
+                     const float *cos, const float *sin, int64_t max_pos,
+                     const void *q_norm_w, const void *k_norm_w, float eps,
+                     void *q_out, void *k_out, void *k_cache, void *v_cache,
+                     const int32_t *slot_mapping, int64_t num_slots, int n_tok,
+                     int n_heads, int n_kv_heads, int head_dim, int dtype,
+                     void *stream);
+
+/* K3 — paged-KV decode attention (one query token per sequence).
+ * Replaces PageAttention.__call__ / flash_attn_with_kvcache
+ * (minivllm/models/layers/page_attention.py:35-133, attention.py:436-447).
+ * q: [B,H,D] token stride q_stride_tok; caches [num_blocks,block_size,Hkv,D];
+ * block_tables int32 [B, >=max_blocks] row stride table_stride, -1 padded;
+ * context_lens int32 [B]; out [B,H,D] contiguous.  Rows with
+ * context_len <= 0 or max_blocks == 0 produce zeros
+ * (page_attention.py:62-65).  Block ids outside [0,num_blocks) inside the
+ * context contribute nothing (reference: zero K/V rows).
+ * workspace: mv_paged_decode_workspace_bytes() bytes, 16-byte aligned. */
+size_t mv_paged_decode_workspace_bytes(int batch, int n_heads, int n_kv_heads,
+                                       int head_dim, int block_size,
+                                       int max_blocks);
+int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *k_cache,
+                    const void *v_cache, const int32_t *block_tables,
+                    int64_t table_stride, const int32_t *context_lens,
+                    void *out, int batch, int n_heads, int n_kv_heads,
+                    int head_dim, int block_size, int max_blocks,
+                    int64_t num_blocks, float scale, void *workspace,
+                    size_t ws_bytes, int dtype, void *stream);
+
+/* K2 — packed varlen causal prefill attention (flash-style, MFMA).
+ * Replaces flash_attn_varlen_func / Attention._fallback_attention
+ * (minivllm/models/layers/attention.py:422-433, :467-504,554-597).
+ * q: [T,H,D] stride q_stride_tok, out [T,H,D] contiguous.
+ * K/V source, exactly one of:
+ *   contiguous: k,v [Tk,Hkv,D] with strides (block_tables == NULL)
+ *   paged:      k_cache/v_cache + block_tables (prefix-cache hit; keys of
+ *               sequence i are its first seqlen_k tokens in the cache)
+ * Causal mask is bottom-right aligned: query j of sequence i (0-based in its
+ * seqlen_q) attends keys 0 .. seqlen_k-seqlen_q+j (attention.py:584-588). */
+int mv_prefill_varlen(const void *q, int64_t q_stride_tok, const void *k,
+                      const void *v, int64_t k_stride_tok, int64_t v_stride_tok,
+                      const void *k_cache, const void *v_cache,
+                      const int32_t *block_tables, int64_t table_stride,
+                      int64_t num_blocks, void *out,
+                      const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
+                      int n_seqs, int max_seqlen_q, int max_seqlen_k,
+                      int n_heads, int n_kv_heads, int head_dim,
+                      int block_size, float scale, int dtype, void *stream);
+
+/* K8 — fused temperature / top-k / top-p / min-p / multinomial sampler.
+ * Replaces Sampler.forward + sampling/functional.py:34-233,410-437 as driven
+ * by InferenceExecutor._sample_tokens (inference_executor.py:776-806).
+ * logits [B,V] row stride ld; temperatures/top_ps/min_ps fp32 [B];
+ * top_ks int64 [B] (<=0 or >=V disables); out_tokens int64 [B].
+ * temperature == 0 -> argmax (lowest index on ties).
+ * RNG: Philox4x32-10 keyed by (seed, offset + *offset_dev, row); offset_dev
+ * (device u64, may be NULL) lets a captured graph draw fresh numbers.
+ * keep_mask (uint8 [B,V], may be NULL) receives the post-filter support set
+ * (1 = kept), for parity tests against the reference's filtered logits. */
+size_t mv_sample_workspace_bytes(int batch, int vocab);
+int mv_sample(const void *logits, int64_t ld, const float *temperatures,
+              const int64_t *top_ks, const float *top_ps, const float *min_ps,
+              uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
+              int64_t *out_tokens, uint8_t *keep_mask, int batch, int vocab,
+              void *workspace, size_t ws_bytes, int dtype, void *stream);
+
+/* K9 — SiluAndMul: out[r, c] = silu(x[r, c]) * x[r, cols + c].
+ * Replaces SiluAndMul.forward (minivllm/models/layers/activation.py:70-96). */
+int mv_silu_and_mul(const void *x, int64_t x_stride, void *out,
+                    int64_t out_stride, int rows, int cols, int dtype,
+                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVHIP_H */

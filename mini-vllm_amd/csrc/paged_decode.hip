@@ -1,0 +1,442 @@
+// K3 — paged-KV decode attention for gfx950
+// (reference: minivllm/models/layers/page_attention.py:35-133 and the
+//  flash_attn_with_kvcache call site, layers/attention.py:436-447).
+//
+// HBM-bound: every K/V byte of a (sequence, kv-head) pair is read exactly
+// once, 16 bytes per lane, LPT = D/VEC adjacent lanes covering one token
+// row (256 contiguous bytes for bf16 D=128), straight into VGPRs.  One
+// workgroup (4 waves) owns one (sequence, kv-head[, head-chunk], split); all
+// G query heads of the kv-head are served from the same K/V registers.
+// Each LPT-lane group runs an independent online softmax over its tokens
+// (no cross-lane traffic in the loop besides the in-row DPP dot-product
+// reduction); groups, waves and splits are merged at the end through
+// shuffles, LDS and (only when split) an fp32 workspace.
+#include "common.h"
+
+
+struct DecodeParams {
+  const void *q;
+  const void *k_cache;
+  const void *v_cache;
+  const int32_t *block_tables;
+  const int32_t *context_lens;
+  void *out;
+  float *ws_acc;  // [B, H, nsplit, D]
+  float *ws_ml;   // [B, H, nsplit, 2]
+  int64_t q_stride;
+  int64_t table_stride;
+  int64_t num_blocks;
+  int n_heads;
+  int n_kv_heads;
+  int g_total;   // q heads per kv head
+  int block_size;
+  int bs_shift;  // log2(block_size) or -1
+  int max_blocks;
+  int nsplit;
+  float scale_log2;  // softmax scale * log2(e)
+};
+
+template <typename Tag>
+__device__ __forceinline__ float dot16B(const u32x4 &a, const u32x4 &b) {
+  float acc = 0.f;
+  if constexpr (__is_same(Tag, bf16_tag)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc = __builtin_amdgcn_fdot2_f32_bf16(u2bf2(a[i]),
+                                            u2bf2(b[i]), acc, false);
+  } else if constexpr (__is_same(Tag, f16_tag)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc = __builtin_amdgcn_fdot2(u2h2(a[i]),
+                                   u2h2(b[i]), acc, false);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc = fmaf(u2f(a[i]), u2f(b[i]), acc);
+  }
+  return acc;
+}
+
+template <typename Tag>
+__device__ __forceinline__ void unpack_vec(const u32x4 &raw, float (&f)[elem<Tag>::VEC]) {
+  if constexpr (elem<Tag>::VEC == 8) {
+    unpack8<Tag>(raw, f);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = u2f(raw[i]);
+  }
+}
+
+// Sum over the LPT adjacent lanes that share one token (LPT in {8,16,32}).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int LPT>
+__device__ __forceinline__ float token_sum(float x) {
+  x += dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]  (xor 1)
+  x += dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]  (xor 2)
+  x += dpp_mov<0x141>(x);  // row_half_mirror      (other quad of the 8)
+  if constexpr (LPT >= 16) x += dpp_mov<0x140>(x);  // row_mirror (other half of the row)
+  if constexpr (LPT >= 32) x += __shfl_xor(x, 16, 64);
+  return x;
+}
+
+template <typename Tag, int D, int G, int NLOAD, bool UNIFORM>
+__global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
+  typedef typename elem<Tag>::T T;
+  constexpr int VEC = elem<Tag>::VEC;
+  constexpr int LPT = D / VEC;       // lanes per token row
+  constexpr int TPL = 64 / LPT;      // tokens per wave-wide load
+  constexpr int TILE = NLOAD * TPL;  // tokens per wave per iteration
+  constexpr int NW = 4;
+  constexpr int UNIT = NW * TILE;
+  constexpr float NEG_BIG = -1e30f;
+
+  __shared__ float lds_ml[NW][G][2];
+  __shared__ float lds_acc[NW][G][D];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int sub = lane % LPT;  // which 16-byte piece of the row
+  const int grp = lane / LPT;  // which token of a wave-wide load
+
+  const int n_chunks = (p.g_total + G - 1) / G;  // q-head chunks per kv head
+  const int hkv = blockIdx.x / n_chunks;
+  const int chunk = blockIdx.x - hkv * n_chunks;
+  const int split = blockIdx.y;
+  const int b = blockIdx.z;
+  const int h0 = hkv * p.g_total + chunk * G;  // first q head of this workgroup
+  const int g_live = min(G, p.g_total - chunk * G);
+
+  int ctx = p.context_lens[b];
+  const int64_t cap = (int64_t)p.max_blocks * p.block_size;
+  if (ctx > cap) ctx = (int)cap;
+  if (ctx < 0) ctx = 0;
+  const int units = (ctx + UNIT - 1) / UNIT;
+  const int ups = (units + p.nsplit - 1) / p.nsplit;
+  const int u_begin = split * ups;
+  const int u_end = min(units, u_begin + ups);
+
+  // q fragments: this lane's 16-byte piece of each of the G heads
+  u32x4 qraw[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int gg = g < g_live ? g : 0;
+    const T *qp = (const T *)p.q + (int64_t)b * p.q_stride + (int64_t)(h0 + gg) * D + sub * VEC;
+    qraw[g] = *reinterpret_cast<const u32x4 *>(qp);
+  }
+
+  float m[G], l[G], acc[G][VEC];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    m[g] = NEG_BIG;
+    l[g] = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[g][j] = 0.f;
+  }
+
+  const int32_t *table = p.block_tables + (int64_t)b * p.table_stride;
+  const int64_t row_stride = (int64_t)p.n_kv_heads * D;  // elements between token rows
+  const T *kbase = (const T *)p.k_cache + (int64_t)hkv * D + sub * VEC;
+  const T *vbase = (const T *)p.v_cache + (int64_t)hkv * D + sub * VEC;
+
+  for (int u = u_begin; u < u_end; ++u) {
+    const int tile_base = (u * NW + wave) * TILE;
+    if (tile_base >= ctx) break;  // wave-uniform
+    u32x4 kraw[NLOAD], vraw[NLOAD];
+    bool valid[NLOAD];
+    int64_t uni_row = -1;
+    if constexpr (UNIFORM) {  // whole tile inside one KV block
+      const int bi = p.bs_shift >= 0 ? (tile_base >> p.bs_shift) : (tile_base / p.block_size);
+      const int blk = bi < p.max_blocks ? __builtin_amdgcn_readfirstlane(table[bi]) : -1;
+      if (blk >= 0 && blk < p.num_blocks)
+        uni_row = (int64_t)blk * p.block_size + (tile_base - bi * p.block_size);
+    }
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int tok = tile_base + i * TPL + grp;
+      int64_t row;
+      bool ok = tok < ctx;
+      if constexpr (UNIFORM) {
+        ok = ok && uni_row >= 0;
+        row = uni_row + i * TPL + grp;
+      } else {
+        const int bi = p.bs_shift >= 0 ? (tok >> p.bs_shift) : (tok / p.block_size);
+        int blk = -1;
+        if (ok && bi < p.max_blocks) blk = table[bi];
+        ok = ok && blk >= 0 && blk < p.num_blocks;
+        row = (int64_t)blk * p.block_size + (tok - bi * p.block_size);
+      }
+      valid[i] = ok;
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      kraw[i] = ok ? *reinterpret_cast<const u32x4 *>(kbase + row * row_stride) : zero;
+      vraw[i] = ok ? *reinterpret_cast<const u32x4 *>(vbase + row * row_stride) : zero;
+    }
+
+    // scores (log2 domain) + online softmax, per query head
+    float pr[G][NLOAD];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float mx = m[g];
+#pragma unroll
+      for (int i = 0; i < NLOAD; ++i) {
+        float s = token_sum<LPT>(dot16B<Tag>(qraw[g], kraw[i])) * p.scale_log2;
+        s = valid[i] ? s : -INFINITY;
+        pr[g][i] = s;
+        mx = fmaxf(mx, s);
+      }
+      const float alpha = __builtin_amdgcn_exp2f(m[g] - mx);
+      m[g] = mx;
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < NLOAD; ++i) {
+        const float e = __builtin_amdgcn_exp2f(pr[g][i] - mx);
+        pr[g][i] = e;
+        ps += e;
+      }
+      l[g] = l[g] * alpha + ps;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[g][j] *= alpha;
+    }
+    // PV
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      float vf[VEC];
+      unpack_vec<Tag>(vraw[i], vf);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[g][j] = fmaf(pr[g][i], vf[j], acc[g][j]);
+    }
+  }
+
+  // merge the TPL lane groups of this wave
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float mm = m[g];
+    for (int off = LPT; off < 64; off <<= 1) mm = fmaxf(mm, __shfl_xor(mm, off, 64));
+    const float f = __builtin_amdgcn_exp2f(m[g] - mm);
+    float ll = l[g] * f;
+    for (int off = LPT; off < 64; off <<= 1) ll += __shfl_xor(ll, off, 64);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float a = acc[g][j] * f;
+      for (int off = LPT; off < 64; off <<= 1) a += __shfl_xor(a, off, 64);
+      acc[g][j] = a;
+    }
+    if (grp == 0) {
+      if (sub == 0) {
+        lds_ml[wave][g][0] = mm;
+        lds_ml[wave][g][1] = ll;
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) lds_acc[wave][g][sub * VEC + j] = acc[g][j];
+    }
+  }
+  __syncthreads();
+
+  // merge the 4 waves; write the output row or this split's partial
+  for (int idx = threadIdx.x; idx < G * D; idx += blockDim.x) {
+    const int g = idx / D, d = idx - g * D;
+    if (g >= g_live) continue;
+    float M = lds_ml[0][g][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, lds_ml[w][g][0]);
+    float L = 0.f, A = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float f = __builtin_amdgcn_exp2f(lds_ml[w][g][0] - M);
+      L += lds_ml[w][g][1] * f;
+      A += lds_acc[w][g][d] * f;
+    }
+    const int h = h0 + g;
+    if (p.nsplit == 1) {
+      const float o = L > 0.f ? A / L : 0.f;
+      ((T *)p.out)[((int64_t)b * p.n_heads + h) * D + d] = elem<Tag>::st(o);
+    } else {
+      const int64_t slot = ((int64_t)b * p.n_heads + h) * p.nsplit + split;
+      p.ws_acc[slot * D + d] = A;
+      if (d == 0) {
+        p.ws_ml[slot * 2 + 0] = M;
+        p.ws_ml[slot * 2 + 1] = L;
+      }
+    }
+  }
+}
+
+template <typename Tag, int D>
+__global__ void paged_decode_reduce_kernel(const float *__restrict__ ws_acc,
+                                           const float *__restrict__ ws_ml,
+                                           typename elem<Tag>::T *__restrict__ out, int nsplit) {
+  const int64_t bh = blockIdx.x;
+  const int d = threadIdx.x;
+  float M = -1e30f;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ws_ml[(bh * nsplit + s) * 2]);
+  float L = 0.f, A = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float f = __builtin_amdgcn_exp2f(ws_ml[(bh * nsplit + s) * 2] - M);
+    L += ws_ml[(bh * nsplit + s) * 2 + 1] * f;
+    A += ws_acc[(bh * nsplit + s) * D + d] * f;
+  }
+  out[bh * D + d] = elem<Tag>::st(L > 0.f ? A / L : 0.f);
+}
+
+// ---- host side -------------------------------------------------------------
+namespace {
+
+struct DecodePlan {
+  int g_chunk;  // q heads served per workgroup (template G)
+  int n_chunks;
+  int nload;
+  int tile;
+  int unit;
+  int nsplit;
+  bool uniform;
+};
+
+constexpr int kTargetWorkgroups = 2048;  // ~8 workgroups per CU
+constexpr int kMaxSplits = 64;
+
+int pick_g(int g_total) {
+  if (g_total <= 8) return g_total;
+  // widest chunk <= 8 that divides evenly, else 8 with a ragged tail
+  for (int g = 8; g >= 4; --g)
+    if (g_total % g == 0) return g;
+  return 8;
+}
+
+bool make_plan(int batch, int n_heads, int n_kv_heads, int head_dim, int block_size,
+               int max_blocks, int dtype, DecodePlan *pl) {
+  if (n_kv_heads <= 0 || n_heads % n_kv_heads) return false;
+  if (head_dim != 64 && head_dim != 128) return false;
+  const int g_total = n_heads / n_kv_heads;
+  pl->g_chunk = pick_g(g_total);
+  pl->n_chunks = (g_total + pl->g_chunk - 1) / pl->g_chunk;
+  const int vec = dtype == MV_F32 ? 4 : 8;
+  const int tpl = 64 / (head_dim / vec);
+  pl->nload = pl->g_chunk <= 4 ? 8 : 4;
+  pl->tile = pl->nload * tpl;
+  pl->unit = 4 * pl->tile;
+  pl->uniform = block_size % pl->tile == 0;
+  const int64_t max_ctx = (int64_t)max_blocks * block_size;
+  const int max_units = (int)((max_ctx + pl->unit - 1) / pl->unit);
+  const int64_t wg = (int64_t)batch * n_kv_heads * pl->n_chunks;
+  int ns = wg > 0 ? (int)((kTargetWorkgroups + wg - 1) / wg) : 1;
+  if (ns > max_units) ns = max_units;
+  if (ns > kMaxSplits) ns = kMaxSplits;
+  if (ns < 1) ns = 1;
+  pl->nsplit = ns;
+  return true;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <typename Tag, int D, int G, int NLOAD>
+void launch_g(const DecodeParams &p, const DecodePlan &pl, int batch, hipStream_t stream) {
+  dim3 grid(p.n_kv_heads * pl.n_chunks, pl.nsplit, batch), block(256);
+  if (pl.uniform)
+    hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, true>), grid, block, 0, stream, p);
+  else
+    hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, false>), grid, block, 0, stream, p);
+}
+
+template <typename Tag, int D>
+int launch_d(const DecodeParams &p, const DecodePlan &pl, int batch, hipStream_t stream) {
+  switch (pl.g_chunk) {
+    case 1: launch_g<Tag, D, 1, 8>(p, pl, batch, stream); break;
+    case 2: launch_g<Tag, D, 2, 8>(p, pl, batch, stream); break;
+    case 3: launch_g<Tag, D, 3, 8>(p, pl, batch, stream); break;
+    case 4: launch_g<Tag, D, 4, 8>(p, pl, batch, stream); break;
+    case 5: launch_g<Tag, D, 5, 4>(p, pl, batch, stream); break;
+    case 6: launch_g<Tag, D, 6, 4>(p, pl, batch, stream); break;
+    case 7: launch_g<Tag, D, 7, 4>(p, pl, batch, stream); break;
+    case 8: launch_g<Tag, D, 8, 4>(p, pl, batch, stream); break;
+    default: return MV_E_SHAPE;
+  }
+  MV_LAUNCH_CHECK();
+  if (pl.nsplit > 1) {
+    hipLaunchKernelGGL((paged_decode_reduce_kernel<Tag, D>), dim3(batch * p.n_heads), dim3(D), 0,
+                       stream, p.ws_acc, p.ws_ml, (typename elem<Tag>::T *)p.out, pl.nsplit);
+    MV_LAUNCH_CHECK();
+  }
+  return MV_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mv_paged_decode_workspace_bytes(int batch, int n_heads, int n_kv_heads,
+                                                  int head_dim, int block_size, int max_blocks) {
+  // sized for the widest element type so one buffer serves every dtype
+  DecodePlan a, b;
+  if (batch <= 0 || !make_plan(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks, MV_BF16, &a) ||
+      !make_plan(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks, MV_F32, &b))
+    return 256;
+  const int ns = a.nsplit > b.nsplit ? a.nsplit : b.nsplit;
+  if (ns <= 1) return 256;
+  const size_t slots = (size_t)batch * n_heads * ns;
+  return align256(slots * head_dim * sizeof(float)) + align256(slots * 2 * sizeof(float));
+}
+
+extern "C" int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *k_cache,
+                               const void *v_cache, const int32_t *block_tables,
+                               int64_t table_stride, const int32_t *context_lens, void *out,
+                               int batch, int n_heads, int n_kv_heads, int head_dim,
+                               int block_size, int max_blocks, int64_t num_blocks, float scale,
+                               void *workspace, size_t ws_bytes, int dtype, void *stream) {
+  if (batch == 0) return MV_OK;
+  if (!q || !out || !context_lens) return MV_E_NULLPTR;
+  if (batch < 0 || n_heads <= 0 || block_size <= 0 || max_blocks < 0 || num_blocks < 0)
+    return MV_E_SHAPE;
+  if (dtype != MV_BF16 && dtype != MV_F16 && dtype != MV_F32) return MV_E_DTYPE;
+  const int esz = dtype == MV_F32 ? 4 : 2;
+  if (max_blocks == 0 || num_blocks == 0) {
+    // reference: zero-column block tables (warm-up) give zeros, page_attention.py:62-65
+    return mv_check_hip(hipMemsetAsync(out, 0, (size_t)batch * n_heads * head_dim * esz,
+                                       (hipStream_t)stream));
+  }
+  if (!k_cache || !v_cache || !block_tables) return MV_E_NULLPTR;
+  DecodePlan pl;
+  if (!make_plan(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks, dtype, &pl))
+    return MV_E_SHAPE;
+  if (!mv_aligned16(q) || !mv_aligned16(k_cache) || !mv_aligned16(v_cache) || !mv_aligned16(out) ||
+      (q_stride_tok * esz) % 16)
+    return MV_E_ALIGN;
+
+  DecodeParams p;
+  p.q = q;
+  p.k_cache = k_cache;
+  p.v_cache = v_cache;
+  p.block_tables = block_tables;
+  p.context_lens = context_lens;
+  p.out = out;
+  p.q_stride = q_stride_tok;
+  p.table_stride = table_stride;
+  p.num_blocks = num_blocks;
+  p.n_heads = n_heads;
+  p.n_kv_heads = n_kv_heads;
+  p.g_total = n_heads / n_kv_heads;
+  p.block_size = block_size;
+  p.bs_shift = (block_size & (block_size - 1)) == 0 ? __builtin_ctz((unsigned)block_size) : -1;
+  p.max_blocks = max_blocks;
+  p.nsplit = pl.nsplit;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.ws_acc = nullptr;
+  p.ws_ml = nullptr;
+  if (pl.nsplit > 1) {
+    const size_t slots = (size_t)batch * n_heads * pl.nsplit;
+    const size_t acc_bytes = align256(slots * head_dim * sizeof(float));
+    const size_t need = acc_bytes + align256(slots * 2 * sizeof(float));
+    if (!workspace) return MV_E_NULLPTR;
+    if (ws_bytes < need || !mv_aligned16(workspace)) return MV_E_WORKSPACE;
+    p.ws_acc = (float *)workspace;
+    p.ws_ml = (float *)((char *)workspace + acc_bytes);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (head_dim == 128) {
+    MV_DISPATCH_DTYPE(dtype, return (launch_d<Tag, 128>(p, pl, batch, st)));
+  } else {
+    MV_DISPATCH_DTYPE(dtype, return (launch_d<Tag, 64>(p, pl, batch, st)));
+  }
+  return MV_OK;
+}

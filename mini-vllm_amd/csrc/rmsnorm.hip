@@ -1,0 +1,188 @@
+// K6 — RMSNorm and fused residual-add + RMSNorm
+// (reference: minivllm/models/layers/layernorm.py:81-105).
+// One workgroup per row; the row lives in registers between the
+// sum-of-squares pass and the scale pass, so HBM sees each element once.
+#include "common.h"
+
+template <typename Tag>
+__device__ __forceinline__ void load_vec(const typename elem<Tag>::T *p, float (&f)[elem<Tag>::VEC]) {
+  const u32x4 raw = *reinterpret_cast<const u32x4 *>(p);
+  if constexpr (elem<Tag>::VEC == 8) {
+    unpack8<Tag>(raw, f);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = u2f(raw[i]);
+  }
+}
+template <typename Tag>
+__device__ __forceinline__ void store_vec(typename elem<Tag>::T *p, const float (&f)[elem<Tag>::VEC]) {
+  u32x4 raw;
+  if constexpr (elem<Tag>::VEC == 8) {
+    raw = pack8<Tag>(f);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) raw[i] = f2u(f[i]);
+  }
+  *reinterpret_cast<u32x4 *>(p) = raw;
+}
+
+// Block-wide sum; every thread gets the total.  `red` holds one float per wave.
+__device__ __forceinline__ float block_sum(float x, float *red) {
+  x = wave_sum(x);
+  const int nw = blockDim.x >> 6;
+  if (nw == 1) return x;
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[w] = x;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// MAXV = 16-byte vectors per thread held in registers.
+template <typename Tag, int MAXV, bool ADD>
+__global__ void rmsnorm_kernel(const typename elem<Tag>::T *__restrict__ x, int64_t x_stride,
+                               typename elem<Tag>::T *residual, int64_t res_stride,
+                               const typename elem<Tag>::T *__restrict__ w,
+                               typename elem<Tag>::T *__restrict__ out, int64_t out_stride,
+                               int cols, float eps) {
+  constexpr int VEC = elem<Tag>::VEC;
+  __shared__ float red[16];
+  const int row = blockIdx.x;
+  const int nvec = cols / VEC;
+  const typename elem<Tag>::T *xr = x + (int64_t)row * x_stride;
+  float vals[MAXV][VEC];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = threadIdx.x + i * blockDim.x;
+    if (c < nvec) {
+      load_vec<Tag>(xr + c * VEC, vals[i]);
+      if constexpr (ADD) {
+        typename elem<Tag>::T *rr = residual + (int64_t)row * res_stride + c * VEC;
+        float r[VEC];
+        load_vec<Tag>(rr, r);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) vals[i][j] = __fadd_rn(vals[i][j], r[j]);
+        store_vec<Tag>(rr, vals[i]);  // residual <- (x + r) -> dtype
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) ss = fmaf(vals[i][j], vals[i][j], ss);
+    }
+  }
+  ss = block_sum(ss, red);
+  const float var = ss / (float)cols;
+  const float rs = 1.0f / sqrtf(var + eps);
+  typename elem<Tag>::T *orow = out + (int64_t)row * out_stride;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = threadIdx.x + i * blockDim.x;
+    if (c < nvec) {
+      float wv[VEC], y[VEC];
+      load_vec<Tag>(w + c * VEC, wv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) y[j] = __fmul_rn(__fmul_rn(vals[i][j], rs), wv[j]);
+      store_vec<Tag>(orow + c * VEC, y);
+    }
+  }
+}
+
+template <typename Tag, bool ADD>
+static int launch_rmsnorm(const void *x, int64_t x_stride, void *residual, int64_t res_stride,
+                          const void *w, void *out, int64_t out_stride, int rows, int cols,
+                          float eps, hipStream_t stream) {
+  typedef typename elem<Tag>::T T;
+  constexpr int VEC = elem<Tag>::VEC;
+  if (cols % VEC) return MV_E_SHAPE;
+  if ((x_stride % VEC) || (out_stride % VEC) || (ADD && (res_stride % VEC))) return MV_E_ALIGN;
+  const int nvec = cols / VEC;
+  int threads = (nvec + 63) / 64 * 64;
+  if (threads > 256) threads = nvec > 1024 ? 1024 : 256;
+  const int per_thread = (nvec + threads - 1) / threads;
+#define MV_RMS_LAUNCH(MV)                                                                        \
+  hipLaunchKernelGGL((rmsnorm_kernel<Tag, MV, ADD>), dim3(rows), dim3(threads), 0, stream,       \
+                     (const T *)x, x_stride, (T *)residual, res_stride, (const T *)w, (T *)out, \
+                     out_stride, cols, eps)
+  if (per_thread <= 1) MV_RMS_LAUNCH(1);
+  else if (per_thread <= 2) MV_RMS_LAUNCH(2);
+  else if (per_thread <= 4) MV_RMS_LAUNCH(4);
+  else if (per_thread <= 8) MV_RMS_LAUNCH(8);
+  else return MV_E_SHAPE;  // > 65536 (16-bit) / 32768 (fp32) columns
+#undef MV_RMS_LAUNCH
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_rmsnorm(const void *x, int64_t x_stride, const void *w, void *out,
+                          int64_t out_stride, int rows, int cols, float eps, int dtype,
+                          void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!x || !w || !out) return MV_E_NULLPTR;
+  if (rows < 0 || cols <= 0) return MV_E_SHAPE;
+  if (!mv_aligned16(x) || !mv_aligned16(w) || !mv_aligned16(out)) return MV_E_ALIGN;
+  MV_DISPATCH_DTYPE(dtype, return (launch_rmsnorm<Tag, false>(x, x_stride, nullptr, 0, w, out, out_stride,
+                                                              rows, cols, eps, (hipStream_t)stream)));
+  return MV_OK;
+}
+
+extern "C" int mv_add_rmsnorm(const void *x, int64_t x_stride, void *residual, int64_t res_stride,
+                              const void *w, void *out, int64_t out_stride, int rows, int cols,
+                              float eps, int dtype, void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!x || !w || !out || !residual) return MV_E_NULLPTR;
+  if (rows < 0 || cols <= 0) return MV_E_SHAPE;
+  if (!mv_aligned16(x) || !mv_aligned16(w) || !mv_aligned16(out) || !mv_aligned16(residual))
+    return MV_E_ALIGN;
+  MV_DISPATCH_DTYPE(dtype, return (launch_rmsnorm<Tag, true>(x, x_stride, residual, res_stride, w, out,
+                                                             out_stride, rows, cols, eps,
+                                                             (hipStream_t)stream)));
+  return MV_OK;
+}
+
+// K9 — SiluAndMul (reference: minivllm/models/layers/activation.py:70-96).
+// The reference rounds silu(x1) to the activation dtype before the multiply;
+// the same two rounding points are kept here.
+template <typename Tag>
+__global__ void __launch_bounds__(256)
+silu_and_mul_kernel(const typename elem<Tag>::T *__restrict__ x, int64_t x_stride,
+                    typename elem<Tag>::T *__restrict__ out, int64_t out_stride, int rows, int cols) {
+  constexpr int VEC = elem<Tag>::VEC;
+  const int nvec = cols / VEC;
+  const int64_t total = (int64_t)rows * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / nvec;
+    const int c = (int)(idx - r * nvec);
+    float a[VEC], b[VEC], y[VEC];
+    load_vec<Tag>(x + r * x_stride + c * VEC, a);
+    load_vec<Tag>(x + r * x_stride + cols + c * VEC, b);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float s = a[j] / (1.0f + expf(-a[j]));
+      s = elem<Tag>::ld(elem<Tag>::st(s));
+      y[j] = __fmul_rn(s, b[j]);
+    }
+    store_vec<Tag>(out + r * out_stride + c * VEC, y);
+  }
+}
+
+extern "C" int mv_silu_and_mul(const void *x, int64_t x_stride, void *out, int64_t out_stride,
+                               int rows, int cols, int dtype, void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!x || !out) return MV_E_NULLPTR;
+  if (rows < 0 || cols <= 0) return MV_E_SHAPE;
+  if (!mv_aligned16(x) || !mv_aligned16(out)) return MV_E_ALIGN;
+  MV_DISPATCH_DTYPE(dtype, {
+    typedef typename elem<Tag>::T T;
+    constexpr int VEC = elem<Tag>::VEC;
+    if (cols % VEC) return MV_E_SHAPE;
+    if ((x_stride % VEC) || (out_stride % VEC)) return MV_E_ALIGN;
+    const int64_t total = (int64_t)rows * (cols / VEC);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL((silu_and_mul_kernel<Tag>), dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, (const T *)x, x_stride, (T *)out, out_stride, rows, cols);
+  });
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}

@@ -1,0 +1,440 @@
+// K8 — fused temperature / top-k / top-p / min-p / multinomial sampler
+// (reference: minivllm/sampling/sampler.py:59-110,
+//  sampling/functional.py:34-233,410-437, driven by
+//  engine/inference_executor.py:776-806).
+//
+// One 1024-thread workgroup per logits row; the row is only ever READ
+// (no sort, no [B,V] temporaries).  All three filters keep a "top set by
+// value", so each one reduces to a threshold on the order-preserving
+// integer key of the raw logit, found by radix select over LDS histograms:
+//   top-k : k-th largest key (count histogram) + how many ties of it to keep
+//   top-p : smallest key v with mass(keys > v) <= p * mass(top-k set)
+//   min-p : weight threshold  exp((x-max)/T) >= min_p
+// then a single multinomial draw (Philox4x32-10) over the surviving weights.
+// Math is fp32 throughout (the reference computes in the logits dtype; see
+// DESIGN.md "sampler parity").
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+
+struct SampleParams {
+  const void *logits;
+  int64_t ld;
+  const float *temperatures;
+  const int64_t *top_ks;
+  const float *top_ps;
+  const float *min_ps;
+  uint64_t seed, offset;
+  const uint64_t *offset_dev;
+  int64_t *out_tokens;
+  uint8_t *keep_mask;
+  int vocab;
+};
+
+struct Shared {
+  float fhist[256];
+  unsigned ihist[256];
+  float fred[kWaves];
+  unsigned ured[kWaves];
+  int ired[kWaves];
+  float fscan[kWaves];
+  unsigned uscan[kWaves];
+  unsigned bcast_u[4];
+  float bcast_f[4];
+};
+
+// ---- Philox4x32-10 -----------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], const uint32_t (&k)[2]) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint32_t row) {
+  uint32_t c[4] = {(uint32_t)offset, (uint32_t)(offset >> 32), row, 0u};
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k);
+    k[0] += 0x9E3779B9u;
+    k[1] += 0xBB67AE85u;
+  }
+  return (float)(c[0] >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+
+// ---- order-preserving keys -----------------------------------------------------
+template <typename Tag> struct keyinfo;
+template <> struct keyinfo<bf16_tag> { static constexpr int BITS = 16; };
+template <> struct keyinfo<f16_tag> { static constexpr int BITS = 16; };
+template <> struct keyinfo<f32_tag> { static constexpr int BITS = 32; };
+
+template <typename Tag>
+__device__ __forceinline__ uint32_t make_key(typename elem<Tag>::T raw) {
+  if constexpr (keyinfo<Tag>::BITS == 16) {
+    const uint32_t u = raw;
+    return (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
+  } else {
+    const uint32_t u = __builtin_bit_cast(uint32_t, raw);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  }
+}
+
+// ---- block-wide helpers (all 1024 threads must call) ------------------------------
+__device__ __forceinline__ float block_max(float x, Shared &sh) {
+  x = wave_max(x);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh.fred[threadIdx.x >> 6] = x;
+  __syncthreads();
+  float r = sh.fred[0];
+#pragma unroll
+  for (int i = 1; i < kWaves; ++i) r = fmaxf(r, sh.fred[i]);
+  return r;
+}
+__device__ __forceinline__ float block_sum_f(float x, Shared &sh) {
+  x = wave_sum(x);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh.fred[threadIdx.x >> 6] = x;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < kWaves; ++i) r += sh.fred[i];
+  return r;
+}
+// exclusive prefix over threads (thread order) + block total
+__device__ __forceinline__ float block_exscan_f(float x, float &total, Shared &sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float inc = x;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float y = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += y;
+  }
+  __syncthreads();
+  if (lane == 63) sh.fscan[w] = inc;
+  __syncthreads();
+  float base = 0.f, tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < kWaves; ++i) {
+    if (i < w) base += sh.fscan[i];
+    tot += sh.fscan[i];
+  }
+  total = tot;
+  return base + inc - x;
+}
+__device__ __forceinline__ unsigned block_exscan_u(unsigned x, unsigned &total, Shared &sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned inc = x;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned y = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += y;
+  }
+  __syncthreads();
+  if (lane == 63) sh.uscan[w] = inc;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kWaves; ++i) {
+    if (i < w) base += sh.uscan[i];
+    tot += sh.uscan[i];
+  }
+  total = tot;
+  return base + inc - x;
+}
+
+// Row walker: thread t owns 16-byte vectors t, t+1024, ... (or single elements
+// when the row is not 16-byte aligned).  Every pass visits a thread's elements
+// in the same order, which is what the tie ranks and the final draw rely on.
+// All threads run the same trip count and call f(index, raw, in_range) with
+// the wave fully converged (f may use cross-lane operations: DPP / bpermute
+// read stale registers from lanes that left a divergent loop).
+template <typename Tag, typename F>
+__device__ __forceinline__ void row_foreach(const typename elem<Tag>::T *row, int vocab, bool vec_ok, F &&f) {
+  typedef typename elem<Tag>::T T;
+  constexpr int VEC = elem<Tag>::VEC;
+  int scalar_from = 0;
+  if (vec_ok) {
+    const int nvec = vocab / VEC;
+    for (int c0 = 0; c0 < nvec; c0 += kThreads) {
+      const int c = c0 + threadIdx.x;
+      const bool ok = c < nvec;
+      u32x4 raw = {0u, 0u, 0u, 0u};
+      if (ok) raw = *reinterpret_cast<const u32x4 *>(row + (int64_t)c * VEC);
+      if constexpr (VEC == 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f(c * VEC + 2 * j, (T)(raw[j] & 0xffffu), ok);
+          f(c * VEC + 2 * j + 1, (T)(raw[j] >> 16), ok);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f(c * VEC + j, u2f(raw[j]), ok);
+      }
+    }
+    scalar_from = nvec * VEC;
+  }
+  for (int i0 = scalar_from; i0 < vocab; i0 += kThreads) {
+    const int i = i0 + threadIdx.x;
+    const bool ok = i < vocab;
+    T raw = (T)0;
+    if (ok) raw = row[i];
+    f(i, raw, ok);
+  }
+}
+
+// LDS histogram add with a cheap wave-level pre-aggregation: logits share a
+// handful of exponents, so in the top digit most lanes of a wave hit the same
+// bin; two "leader bin" rounds take those out before the plain atomics.
+template <typename V>
+__device__ __forceinline__ void hist_add(V *hist, bool active, unsigned bin, V val) {
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const unsigned long long m = __ballot(active);
+    if (m == 0) return;
+    const int leader = __ffsll((long long)m) - 1;
+    const unsigned lb = __shfl((int)bin, leader, 64);
+    const bool mine = active && bin == lb;
+    V part = mine ? val : (V)0;
+    // wave_sum for float, integer butterfly for counts
+    if constexpr (__is_same(V, float)) {
+      part = wave_sum(part);
+    } else {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+    }
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lb], part);
+    active = active && !mine;
+  }
+  if (active) atomicAdd(&hist[bin], val);
+}
+
+template <typename Tag>
+__global__ void __launch_bounds__(kThreads) sample_kernel(SampleParams p) {
+  typedef typename elem<Tag>::T T;
+  constexpr int KBITS = keyinfo<Tag>::BITS;
+  constexpr int LEVELS = KBITS / 8;
+  __shared__ Shared sh;
+
+  const int rowi = blockIdx.x;
+  const int V = p.vocab;
+  const T *row = (const T *)p.logits + (int64_t)rowi * p.ld;
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+  uint8_t *mask_row = p.keep_mask ? p.keep_mask + (int64_t)rowi * V : nullptr;
+  const float temp = p.temperatures ? p.temperatures[rowi] : 1.0f;
+
+  // ---- pass A: max (and argmax, lowest index on ties) ------------------------------
+  float best = -INFINITY;
+  int best_i = 0x7fffffff;
+  row_foreach<Tag>(row, V, vec_ok, [&](int i, T raw, bool ok) {
+    const float x = elem<Tag>::ld(raw);
+    if (ok && (x > best || (x == best && i < best_i))) { best = x; best_i = i; }
+  });
+  const float xmax = block_max(best, sh);
+  if (temp == 0.0f) {  // greedy (argmax, not multinomial over softmax(l/1e-8))
+    int cand = (best == xmax) ? best_i : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cand = min(cand, __shfl_xor(cand, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.ired[threadIdx.x >> 6] = cand;
+    __syncthreads();
+    int win = sh.ired[0];
+#pragma unroll
+    for (int i = 1; i < kWaves; ++i) win = min(win, sh.ired[i]);
+    if (win == 0x7fffffff) win = 0;  // all-NaN row
+    if (threadIdx.x == 0) p.out_tokens[rowi] = win;
+    if (mask_row)
+      for (int i = threadIdx.x; i < V; i += kThreads) mask_row[i] = (i == win);
+    return;
+  }
+
+  const bool degenerate = !(xmax > -INFINITY) || !(xmax < INFINITY);  // all -inf / NaN / +inf
+  const float inv_t = 1.4426950408889634f / fmaxf(temp, 1e-8f);
+  auto weight = [&](float x) -> float {
+    return degenerate ? 1.0f : __builtin_amdgcn_exp2f((x - xmax) * inv_t);
+  };
+
+  // ---- top-k: k-th largest key, and how many of its ties to keep ----------------------
+  const int64_t k_raw = p.top_ks ? p.top_ks[rowi] : -1;
+  const bool topk_on = !degenerate && k_raw > 0 && k_raw < (int64_t)V;
+  uint32_t key_k = 0;        // keep key > key_k, plus `need_ties` elements with key == key_k
+  unsigned need_ties = 0;
+  bool ties_partial = false; // true when only some of the ties survive
+  unsigned tie_before = 0;   // this thread's first tie rank (thread-major order)
+  if (topk_on) {
+    uint32_t prefix = 0;
+    unsigned above = 0;      // elements with a strictly larger prefix
+    unsigned bin_count = 0;
+    for (int lvl = 0; lvl < LEVELS; ++lvl) {
+      const int shift = KBITS - 8 * (lvl + 1);
+      __syncthreads();
+      if (threadIdx.x < 256) sh.ihist[threadIdx.x] = 0;
+      __syncthreads();
+      row_foreach<Tag>(row, V, vec_ok, [&](int i, T raw, bool ok) {
+        const uint32_t key = make_key<Tag>(raw);
+        const bool in = ok && (lvl == 0 || (key >> (shift + 8)) == prefix);
+        hist_add<unsigned>(sh.ihist, in, (key >> shift) & 0xffu, 1u);
+      });
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned c = above;
+        int d = 255;
+        for (; d > 0; --d) {
+          if (c + sh.ihist[d] >= (unsigned)k_raw) break;
+          c += sh.ihist[d];
+        }
+        sh.bcast_u[0] = (unsigned)d;
+        sh.bcast_u[1] = c;
+        sh.bcast_u[2] = sh.ihist[d];
+      }
+      __syncthreads();
+      prefix = (prefix << 8) | sh.bcast_u[0];
+      above = sh.bcast_u[1];
+      bin_count = sh.bcast_u[2];
+    }
+    key_k = prefix;
+    need_ties = (unsigned)k_raw - above;  // 1 <= need_ties <= bin_count
+    ties_partial = need_ties < bin_count;
+    if (ties_partial) {
+      unsigned mine = 0;
+      row_foreach<Tag>(row, V, vec_ok, [&](int i, T raw, bool ok) { mine += ok && make_key<Tag>(raw) == key_k; });
+      unsigned tot;
+      tie_before = block_exscan_u(mine, tot, sh);
+    }
+  }
+  // membership in the top-k set; `tie_seen` must be reset to 0 before every pass
+  unsigned tie_seen = 0;
+  auto in_topk = [&](uint32_t key) -> bool {
+    if (!topk_on) return true;
+    if (key > key_k) return true;
+    if (key < key_k) return false;
+    if (!ties_partial) return true;
+    return (tie_before + tie_seen++) < need_ties;
+  };
+
+  // ---- top-p: smallest key v with mass(key > v) <= p * Z1 -----------------------------
+  const float top_p = p.top_ps ? p.top_ps[rowi] : 1.0f;
+  const bool topp_on = !degenerate && top_p < 1.0f;
+  uint32_t key_p = 0;  // keep key >= key_p
+  if (topp_on) {
+    float z = 0.f;
+    tie_seen = 0;
+    row_foreach<Tag>(row, V, vec_ok, [&](int i, T raw, bool ok) {
+      if (ok && in_topk(make_key<Tag>(raw))) z += weight(elem<Tag>::ld(raw));
+    });
+    const float budget = top_p * block_sum_f(z, sh);
+    uint32_t prefix = 0;
+    float above = 0.f;
+    for (int lvl = 0; lvl < LEVELS; ++lvl) {
+      const int shift = KBITS - 8 * (lvl + 1);
+      __syncthreads();
+      if (threadIdx.x < 256) sh.fhist[threadIdx.x] = 0.f;
+      __syncthreads();
+      tie_seen = 0;
+      row_foreach<Tag>(row, V, vec_ok, [&](int i, T raw, bool ok) {
+        const uint32_t key = make_key<Tag>(raw);
+        const bool member = ok && in_topk(key);
+        const bool in = member && (lvl == 0 || (key >> (shift + 8)) == prefix);
+        hist_add<float>(sh.fhist, in, (key >> shift) & 0xffu, in ? weight(elem<Tag>::ld(raw)) : 0.f);
+      });
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        // walk down while everything strictly above the NEXT bin still fits the budget
+        float c = above;
+        int d = 255;
+        for (; d > 0; --d) {
+          const float next = c + sh.fhist[d];
+          if (!(next <= budget)) break;
+          c = next;
+        }
+        sh.bcast_u[0] = (unsigned)d;
+        sh.bcast_f[0] = c;
+      }
+      __syncthreads();
+      prefix = (prefix << 8) | sh.bcast_u[0];
+      above = sh.bcast_f[0];
+    }
+    key_p = prefix;
+  }
+
+  // ---- min-p: prob < min_p * max_prob  <=>  weight < min_p  (the normaliser cancels) ----
+  const float min_p = p.min_ps ? p.min_ps[rowi] : 0.0f;
+  const bool minp_on = !degenerate && min_p > 0.0f;
+
+  auto kept = [&](uint32_t key, float w) -> bool {
+    bool k = in_topk(key);
+    if (topp_on) k = k && key >= key_p;
+    if (minp_on) k = k && !(w < min_p);
+    return k;
+  };
+
+  // ---- final: per-thread mass, exclusive scan in thread order, one draw -----------------
+  float mine = 0.f;
+  tie_seen = 0;
+  row_foreach<Tag>(row, V, vec_ok, [&](int i, T raw, bool ok) {
+    const float w = weight(elem<Tag>::ld(raw));
+    const bool k = ok && kept(make_key<Tag>(raw), w);
+    if (ok && mask_row) mask_row[i] = k;
+    if (k) mine += w;
+  });
+  float total;
+  const float before = block_exscan_f(mine, total, sh);
+  const uint64_t off = p.offset + (p.offset_dev ? *p.offset_dev : 0ull);
+  const float target = philox_uniform(p.seed, off, (uint32_t)rowi) * total;
+
+  // owner = last thread whose prefix <= target and that holds mass
+  __syncthreads();
+  if (threadIdx.x == 0) sh.bcast_u[3] = 0u;
+  __syncthreads();
+  const bool owner = mine > 0.f && before <= target;
+  if (owner) atomicMax(&sh.bcast_u[3], (unsigned)threadIdx.x + 1u);
+  __syncthreads();
+  const unsigned who = sh.bcast_u[3] ? sh.bcast_u[3] - 1u : 0u;
+  if (threadIdx.x == who) {
+    float run = before;
+    int pick = -1, last_kept = -1;
+    tie_seen = 0;
+    row_foreach<Tag>(row, V, vec_ok, [&](int i, T raw, bool ok) {
+      const float w = weight(elem<Tag>::ld(raw));
+      if (ok && kept(make_key<Tag>(raw), w)) {
+        last_kept = i;
+        run += w;
+        if (pick < 0 && run > target) pick = i;
+      }
+    });
+    if (pick < 0) pick = last_kept >= 0 ? last_kept : best_i;  // rounding at the very end
+    if (pick < 0 || pick >= V) pick = 0;
+    p.out_tokens[rowi] = pick;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t mv_sample_workspace_bytes(int batch, int vocab) {
+  (void)batch; (void)vocab;
+  return 256;  // the kernel keeps everything in LDS/registers; reserved for future use
+}
+
+extern "C" int mv_sample(const void *logits, int64_t ld, const float *temperatures,
+                         const int64_t *top_ks, const float *top_ps, const float *min_ps,
+                         uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
+                         int64_t *out_tokens, uint8_t *keep_mask, int batch, int vocab,
+                         void *workspace, size_t ws_bytes, int dtype, void *stream) {
+  (void)workspace; (void)ws_bytes;
+  if (batch == 0) return MV_OK;
+  if (!logits || !out_tokens) return MV_E_NULLPTR;
+  if (batch < 0 || vocab <= 0 || ld < vocab) return MV_E_SHAPE;
+  SampleParams p;
+  p.logits = logits; p.ld = ld; p.temperatures = temperatures; p.top_ks = top_ks;
+  p.top_ps = top_ps; p.min_ps = min_ps; p.seed = seed; p.offset = offset;
+  p.offset_dev = offset_dev; p.out_tokens = out_tokens; p.keep_mask = keep_mask; p.vocab = vocab;
+  MV_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sample_kernel<Tag>), dim3(batch), dim3(kThreads), 0,
+                                              (hipStream_t)stream, p));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}

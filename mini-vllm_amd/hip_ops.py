@@ -1,0 +1,316 @@
+"""ctypes binding of libmvhip.so (include/mvhip.h) for torch tensors.
+
+This is the only place the Python host touches the C-ABI.  Every wrapper
+launches on torch's *current* stream, so the calls are captured by
+``torch.cuda.graph`` (= hipGraph) like any torch op.  There is no fallback:
+if the shared library is missing, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmvhip.so")
+
+MV_BF16, MV_F16, MV_F32 = 0, 1, 2
+_DTYPES = {torch.bfloat16: MV_BF16, torch.float16: MV_F16, torch.float32: MV_F32}
+
+# name -> (restype, argtypes); mirrors include/mvhip.h one-to-one
+_SIGNATURES = {
+    "mv_version": (c_int, []),
+    "mv_strerror": (c_char_p, [c_int]),
+    "mv_store_kvcache": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                 c_int, c_int, c_int, c_int64, c_int, c_void_p]),
+    "mv_rmsnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_float,
+                           c_int, c_void_p]),
+    "mv_add_rmsnorm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                               c_int, c_int, c_float, c_int, c_void_p]),
+    "mv_rope_qk_store": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                 c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                 c_int, c_int, c_void_p]),
+    "mv_paged_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mv_paged_decode": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_float,
+                                c_void_p, c_size_t, c_int, c_void_p]),
+    "mv_prefill_varlen": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+                                  c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                  c_void_p]),
+    "mv_sample_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mv_sample": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
+                          c_uint64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t,
+                          c_int, c_void_p]),
+    "mv_silu_and_mul": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class MvHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise MvHipError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C mini-vllm_amd/csrc`). "
+            "There is no CPU fallback for the GPU hot path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError => ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = _load()
+
+
+def lib():
+    return _lib
+
+
+def version() -> int:
+    return int(_lib.mv_version())
+
+
+def _check(code: int, what: str) -> None:
+    if code != 0:
+        msg = _lib.mv_strerror(code)
+        raise MvHipError(f"{what} failed: [{code}] {msg.decode() if msg else '?'}")
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise MvHipError(f"unsupported dtype {t.dtype}") from None
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise MvHipError("libmvhip kernels need device tensors (got a CPU tensor); "
+                             "the product path has no CPU fallback")
+
+
+def _i32(t):
+    if t is None:
+        return None
+    return t if t.dtype == torch.int32 else t.to(torch.int32)
+
+
+# ---------------------------------------------------------------- workspace
+_workspace: dict[int, torch.Tensor] = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only per-device scratch buffer (allocate before graph capture)."""
+    idx = torch.device(device).index or 0
+    buf = _workspace.get(idx)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspace[idx] = buf
+    return buf
+
+
+# ---------------------------------------------------------------- K1
+def store_kvcache(key, value, k_cache, v_cache, slot_mapping) -> None:
+    """key/value [N,Hkv,D] (last two dims dense), caches [nb,bs,Hkv,D] contiguous."""
+    _need_cuda(key, value, k_cache, v_cache, slot_mapping)
+    n, hkv, d = key.shape
+    if slot_mapping.numel() != n:
+        raise ValueError(f"slot_mapping size {slot_mapping.numel()} != batch_size {n}")
+    if key.stride(-1) != 1 or key.stride(1) != d or value.stride(-1) != 1 or value.stride(1) != d:
+        raise MvHipError("key/value must be dense in their last two dims")
+    if key.dtype != k_cache.dtype:
+        key, value = key.to(k_cache.dtype), value.to(v_cache.dtype)
+    if not (k_cache.is_contiguous() and v_cache.is_contiguous()):
+        raise MvHipError("KV cache must be contiguous")
+    num_slots = k_cache.numel() // (hkv * d)
+    _check(_lib.mv_store_kvcache(key.data_ptr(), value.data_ptr(), key.stride(0), value.stride(0),
+                                 k_cache.data_ptr(), v_cache.data_ptr(), _i32(slot_mapping).data_ptr(),
+                                 n, hkv, d, num_slots, _dt(k_cache), _stream()), "mv_store_kvcache")
+
+
+# ---------------------------------------------------------------- K6
+def _rows2d(x):
+    cols = x.shape[-1]
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    x2 = x.reshape(-1, cols)  # view when possible
+    return x2, cols
+
+
+def rmsnorm(x, weight, eps: float):
+    _need_cuda(x, weight)
+    x2, cols = _rows2d(x)
+    out = torch.empty((x2.shape[0], cols), dtype=x.dtype, device=x.device)
+    w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+    _check(_lib.mv_rmsnorm(x2.data_ptr(), x2.stride(0), w.data_ptr(), out.data_ptr(), out.stride(0),
+                           x2.shape[0], cols, float(eps), _dt(x), _stream()), "mv_rmsnorm")
+    return out.view(x.shape)
+
+
+def add_rmsnorm(x, residual, weight, eps: float, inplace: bool = True):
+    """Returns (normed, new_residual).  With inplace=True ``residual`` is overwritten
+    by the rounded sum (the reference allocates a new tensor, layernorm.py:95-105)."""
+    _need_cuda(x, residual, weight)
+    x2, cols = _rows2d(x)
+    res = residual if inplace else residual.clone()
+    if not res.is_contiguous():
+        res = res.contiguous()
+    r2 = res.view(-1, cols)
+    out = torch.empty((x2.shape[0], cols), dtype=x.dtype, device=x.device)
+    w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+    _check(_lib.mv_add_rmsnorm(x2.data_ptr(), x2.stride(0), r2.data_ptr(), r2.stride(0), w.data_ptr(),
+                               out.data_ptr(), out.stride(0), x2.shape[0], cols, float(eps), _dt(x),
+                               _stream()), "mv_add_rmsnorm")
+    return out.view(x.shape), res.view(residual.shape)
+
+
+# ---------------------------------------------------------------- K7
+def rope_qk_store(q, k, v, positions, cos, sin, q_norm_w=None, k_norm_w=None, eps: float = 1e-6,
+                  k_cache=None, v_cache=None, slot_mapping=None, want_k_out: bool = True):
+    """q [T,H,D], k/v [T,Hkv,D] (views of the qkv GEMM output are fine).
+    Returns (q_rot [T,H,D], k_rot [T,Hkv,D] or None)."""
+    _need_cuda(q, k, positions, cos, sin)
+    t, h, d = q.shape
+    hkv = k.shape[1]
+    for name, x in (("q", q), ("k", k), ("v", v)):
+        if x is not None and (x.stride(-1) != 1 or x.stride(1) != d):
+            raise MvHipError(f"{name} must be dense in its last two dims")
+    q_out = torch.empty((t, h, d), dtype=q.dtype, device=q.device)
+    k_out = torch.empty((t, hkv, d), dtype=q.dtype, device=q.device) if want_k_out else None
+    has_cache = k_cache is not None and k_cache.numel() > 0 and slot_mapping is not None \
+        and slot_mapping.numel() > 0
+    num_slots = 0
+    if has_cache:
+        if k_cache.dtype != q.dtype:
+            raise MvHipError("q/k/v dtype must equal the KV-cache dtype")
+        num_slots = k_cache.numel() // (hkv * d)
+        if slot_mapping.numel() != t:
+            raise ValueError(f"slot_mapping size {slot_mapping.numel()} != batch_size {t}")
+    pos = positions if positions.dtype == torch.int64 else positions.to(torch.int64)
+    qn = q_norm_w if q_norm_w is None or q_norm_w.dtype == q.dtype else q_norm_w.to(q.dtype)
+    kn = k_norm_w if k_norm_w is None or k_norm_w.dtype == q.dtype else k_norm_w.to(q.dtype)
+    _check(_lib.mv_rope_qk_store(
+        q.data_ptr(), k.data_ptr(), _ptr(v), q.stride(0), k.stride(0), v.stride(0) if v is not None else 0,
+        pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), cos.shape[0], _ptr(qn), _ptr(kn), float(eps),
+        q_out.data_ptr(), _ptr(k_out),
+        k_cache.data_ptr() if has_cache else None, v_cache.data_ptr() if has_cache else None,
+        _i32(slot_mapping).data_ptr() if has_cache else None, num_slots, t, h, hkv, d, _dt(q),
+        _stream()), "mv_rope_qk_store")
+    return q_out, k_out
+
+
+# ---------------------------------------------------------------- K3
+def paged_decode_workspace_bytes(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks) -> int:
+    return int(_lib.mv_paged_decode_workspace_bytes(batch, n_heads, n_kv_heads, head_dim, block_size,
+                                                    max_blocks))
+
+
+def paged_decode(q, k_cache, v_cache, block_tables, context_lens, scale: float, out=None):
+    """q [B,H,D]; caches [nb,bs,Hkv,D]; block_tables int [B,nblk] (row-strided view ok);
+    context_lens int [B].  Returns [B,H,D] in q's dtype."""
+    _need_cuda(q, k_cache, v_cache, block_tables, context_lens)
+    b, h, d = q.shape
+    if q.stride(-1) != 1 or q.stride(1) != d:
+        q = q.contiguous()
+    if out is None:
+        out = torch.empty((b, h, d), dtype=q.dtype, device=q.device)
+    nb, bs, hkv = k_cache.shape[0], k_cache.shape[1], k_cache.shape[2]
+    bt = _i32(block_tables)
+    if bt.dim() != 2 or (bt.shape[1] > 0 and bt.stride(1) != 1):
+        bt = bt.contiguous()
+    cl = _i32(context_lens)
+    max_blocks = bt.shape[1]
+    ws_bytes = paged_decode_workspace_bytes(b, h, hkv, d, bs, max_blocks)
+    ws = workspace(ws_bytes, q.device)
+    _check(_lib.mv_paged_decode(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(),
+                                bt.data_ptr(), bt.stride(0) if max_blocks else 0, cl.data_ptr(),
+                                out.data_ptr(), b, h, hkv, d, bs, max_blocks, nb, float(scale),
+                                ws.data_ptr(), ws.numel(), _dt(q), _stream()), "mv_paged_decode")
+    return out
+
+
+# ---------------------------------------------------------------- K2
+def prefill_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, scale: float,
+                   k_cache=None, v_cache=None, block_tables=None, out=None):
+    """Packed causal prefill.  Contiguous K/V (k,v [Tk,Hkv,D]) unless ``block_tables`` is
+    given, in which case keys come from the paged caches (prefix-cache hit)."""
+    _need_cuda(q, cu_seqlens_q, cu_seqlens_k)
+    t, h, d = q.shape
+    if q.stride(-1) != 1 or q.stride(1) != d:
+        q = q.contiguous()
+    if out is None:
+        out = torch.empty((t, h, d), dtype=q.dtype, device=q.device)
+    n_seqs = cu_seqlens_q.numel() - 1
+    paged = block_tables is not None
+    if paged:
+        nb, bs, hkv = k_cache.shape[0], k_cache.shape[1], k_cache.shape[2]
+        bt = _i32(block_tables)
+        if bt.stride(1) != 1:
+            bt = bt.contiguous()
+        args_kv = (None, None, 0, 0, k_cache.data_ptr(), v_cache.data_ptr(), bt.data_ptr(), bt.stride(0), nb)
+    else:
+        hkv = k.shape[1]
+        bs = 0
+        for name, x in (("k", k), ("v", v)):
+            if x.stride(-1) != 1 or x.stride(1) != d:
+                raise MvHipError(f"{name} must be dense in its last two dims")
+        args_kv = (k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0), None, None, None, 0, 0)
+    _check(_lib.mv_prefill_varlen(q.data_ptr(), q.stride(0), *args_kv, out.data_ptr(),
+                                  _i32(cu_seqlens_q).data_ptr(), _i32(cu_seqlens_k).data_ptr(), n_seqs,
+                                  int(max_seqlen_q), int(max_seqlen_k), h, hkv, d, bs, float(scale),
+                                  _dt(q), _stream()), "mv_prefill_varlen")
+    return out
+
+
+# ---------------------------------------------------------------- K8
+def sample(logits, temperatures, top_ks, top_ps, min_ps, seed: int = 0, offset: int = 0,
+           offset_dev=None, return_mask: bool = False):
+    """logits [B,V]; per-row params [B].  Returns int64 tokens [B] (and the uint8 keep mask)."""
+    _need_cuda(logits, temperatures, top_ks, top_ps, min_ps)
+    b, v = logits.shape
+    if logits.stride(-1) != 1:
+        logits = logits.contiguous()
+    out = torch.empty((b,), dtype=torch.int64, device=logits.device)
+    mask = torch.empty((b, v), dtype=torch.uint8, device=logits.device) if return_mask else None
+
+    def f32(x):
+        return None if x is None else (x if x.dtype == torch.float32 else x.float())
+    tk = None if top_ks is None else (top_ks if top_ks.dtype == torch.int64 else top_ks.to(torch.int64))
+    temperatures, top_ps, min_ps = f32(temperatures), f32(top_ps), f32(min_ps)
+    _check(_lib.mv_sample(logits.data_ptr(), logits.stride(0), _ptr(temperatures), _ptr(tk), _ptr(top_ps),
+                          _ptr(min_ps), int(seed) & (2**64 - 1), int(offset) & (2**64 - 1),
+                          _ptr(offset_dev), out.data_ptr(), _ptr(mask), b, v, None, 0, _dt(logits),
+                          _stream()), "mv_sample")
+    return (out, mask) if return_mask else out
+
+
+# ---------------------------------------------------------------- K9
+def silu_and_mul(x):
+    _need_cuda(x)
+    if x.size(-1) % 2 != 0:
+        raise ValueError(f"Input last dimension must be even for SiluAndMul, got {x.size(-1)}")
+    x2, cols2 = _rows2d(x)
+    cols = cols2 // 2
+    out = torch.empty((x2.shape[0], cols), dtype=x.dtype, device=x.device)
+    _check(_lib.mv_silu_and_mul(x2.data_ptr(), x2.stride(0), out.data_ptr(), out.stride(0), x2.shape[0],
+                                cols, _dt(x), _stream()), "mv_silu_and_mul")
+    return out.view(*x.shape[:-1], cols)

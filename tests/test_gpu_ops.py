@@ -1,0 +1,385 @@
+"""GPU parity: every libmvhip.so kernel, called through the C-ABI (ctypes), against the
+CPU oracle on the same seeded inputs.  Integer/byte work is bit-exact; floating point is
+held to the tolerance written next to each check."""
+import math
+
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def H():
+    from minivllm_amd import hip_ops
+
+    return hip_ops
+
+
+def _randn(*shape, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float32).to(dtype)
+
+
+def _tol(dtype):
+    # fp32: the reference's own unit-test tolerance (tests/test_page_attention.py:120)
+    # bf16/f16: 2 ulp of the output scale (outputs are O(1))
+    return {torch.float32: dict(rtol=1e-4, atol=1e-5),
+            torch.bfloat16: dict(rtol=2 ** -7, atol=2 ** -7),
+            torch.float16: dict(rtol=2 ** -10, atol=2 ** -9)}[dtype]
+
+
+def _make_paged(B, Hkv, D, bs, ctxs, dtype, seed, nb_extra=3, pad_cols=2):
+    """Random caches + a shuffled (non-contiguous) block table, -1 padded."""
+    g = torch.Generator().manual_seed(seed)
+    nblk = [(c + bs - 1) // bs for c in ctxs]
+    total = sum(nblk) + nb_extra
+    perm = torch.randperm(total, generator=g).tolist()
+    width = max(nblk + [1]) + pad_cols
+    table = torch.full((B, width), -1, dtype=torch.int32)
+    it = iter(perm)
+    for b in range(B):
+        for j in range(nblk[b]):
+            table[b, j] = next(it)
+    kc = torch.randn(total, bs, Hkv, D, generator=g).to(dtype)
+    vc = torch.randn(total, bs, Hkv, D, generator=g).to(dtype)
+    return kc, vc, table
+
+
+# ------------------------------------------------------------------ K1
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_store_kvcache_bit_exact(H, dtype):
+    n, Hq, Hkv, D, nb, bs = 37, 4, 2, 128, 5, 64
+    qkv = _randn(n, (Hq + 2 * Hkv) * D, dtype=dtype, seed=1)
+    k = qkv[:, Hq * D:(Hq + Hkv) * D].view(n, Hkv, D)        # strided views, like the engine
+    v = qkv[:, (Hq + Hkv) * D:].view(n, Hkv, D)
+    slots = torch.randperm(nb * bs, generator=torch.Generator().manual_seed(2))[:n].to(torch.int32)
+    slots[3] = -1
+    slots[11] = -1
+    kc0 = _randn(nb, bs, Hkv, D, dtype=dtype, seed=3)
+    vc0 = _randn(nb, bs, Hkv, D, dtype=dtype, seed=4)
+    kc_ref, vc_ref = kc0.clone(), vc0.clone()
+    O.store_kvcache(k, v, kc_ref, vc_ref, slots)
+    kc, vc = kc0.to(DEV), vc0.to(DEV)
+    qkv_d = qkv.to(DEV)
+    kd = qkv_d[:, Hq * D:(Hq + Hkv) * D].view(n, Hkv, D)
+    vd = qkv_d[:, (Hq + Hkv) * D:].view(n, Hkv, D)
+    H.store_kvcache(kd, vd, kc, vc, slots.to(DEV))
+    assert torch.equal(kc.cpu(), kc_ref)
+    assert torch.equal(vc.cpu(), vc_ref)
+
+
+def test_store_kvcache_int64_slots_and_size_check(H):
+    k = torch.zeros(4, 2, 64, dtype=torch.bfloat16, device=DEV)
+    kc = torch.zeros(2, 64, 2, 64, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    H.store_kvcache(k + 1, k + 2, kc, vc, torch.tensor([5, -1, 70, 127], device=DEV))  # int64 ok
+    assert float(kc.view(-1, 128)[5].sum()) == 128.0 and float(vc.view(-1, 128)[127].sum()) == 256.0
+    assert float(kc.view(-1, 128)[0].sum()) == 0.0
+    with pytest.raises(ValueError):
+        H.store_kvcache(k, k, kc, vc, torch.tensor([1, 2], device=DEV))
+
+
+# ------------------------------------------------------------------ K3
+DECODE_CASES = [
+    # B, H, Hkv, D, bs, ctxs
+    (3, 16, 8, 128, 64, [1, 64, 200]),          # Qwen3 head layout, boundary lengths
+    (4, 28, 4, 128, 64, [130, 4, 777, 65]),     # Qwen2-7B: G = 7
+    (2, 8, 1, 128, 64, [300, 1023]),            # 72B@TP8 per-GPU: G = 8
+    (2, 12, 12, 64, 64, [90, 17]),              # OPT: MHA, D = 64
+    (2, 8, 2, 128, 16, [33, 95]),               # small block size (reference unit tests)
+    (2, 32, 2, 128, 64, [257, 31]),             # G = 16 -> two head chunks
+    (1, 16, 8, 128, 64, [4096]),                # long context, split-KV
+    (5, 4, 2, 64, 4, [1, 2, 3, 9, 40]),         # tiny blocks, generic (non-uniform) path
+]
+
+
+@pytest.mark.parametrize("case", DECODE_CASES, ids=[f"case{i}" for i in range(len(DECODE_CASES))])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+def test_paged_decode_vs_oracle(H, case, dtype):
+    B, Hq, Hkv, D, bs, ctxs = case
+    kc, vc, table = _make_paged(B, Hkv, D, bs, ctxs, dtype, seed=10 + B)
+    q = _randn(B, Hq, D, dtype=dtype, seed=99)
+    ctx = torch.tensor(ctxs, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(D)
+    ref = O.paged_decode(q, kc, vc, table, ctx, scale)
+    out = H.paged_decode(q.to(DEV), kc.to(DEV), vc.to(DEV), table.to(DEV), ctx.to(DEV), scale)
+    assert out.dtype == dtype and out.shape == (B, Hq, D)
+    torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
+
+
+def test_paged_decode_edge_cases(H):
+    dtype = torch.bfloat16
+    B, Hq, Hkv, D, bs = 4, 16, 8, 128, 64
+    kc, vc, table = _make_paged(B, Hkv, D, bs, [64, 10, 128, 5], dtype, seed=5)
+    q = _randn(B, Hq, D, dtype=dtype, seed=6)
+    scale = D ** -0.5
+    # (a) ctx == 0 rows (graph-replay padding) give zeros and touch nothing
+    ctx = torch.tensor([64, 0, 128, 0], dtype=torch.int32)
+    out = H.paged_decode(q.to(DEV), kc.to(DEV), vc.to(DEV), table.to(DEV), ctx.to(DEV), scale)
+    ref = O.paged_decode(q, kc, vc, table, ctx, scale)
+    torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
+    assert float(out[1].abs().sum()) == 0.0 and float(out[3].abs().sum()) == 0.0
+    # (b) zero-column block table (warm-up decode): zeros, page_attention.py:62-65
+    out0 = H.paged_decode(q.to(DEV), kc.to(DEV), vc.to(DEV),
+                          torch.empty(B, 0, dtype=torch.int32, device=DEV), ctx.to(DEV), scale)
+    assert float(out0.abs().sum()) == 0.0
+    # (c) int64 tables / context_lens (reference unit tests pass int64) and a row-strided view
+    big = torch.full((8, 16), -1, dtype=torch.int64)
+    big[:B, :table.shape[1]] = table.long()
+    view = big.to(DEV)[:B, :table.shape[1]]
+    ctx2 = torch.tensor([64, 10, 128, 5], dtype=torch.int64)
+    out2 = H.paged_decode(q.to(DEV), kc.to(DEV), vc.to(DEV), view, ctx2.to(DEV), scale)
+    ref2 = O.paged_decode(q, kc, vc, table, ctx2, scale)
+    torch.testing.assert_close(out2.float().cpu(), ref2, **_tol(dtype))
+
+
+def test_paged_decode_large_batch_property(H):
+    """BASELINE config-3 shape (B=256, ctx=1024): checked through a size-independent
+    property — permuting the physical blocks (and the table with them) must not change a bit."""
+    dtype = torch.bfloat16
+    B, Hq, Hkv, D, bs, ctxlen = 256, 16, 8, 128, 64, 1024
+    nblk = ctxlen // bs
+    nb = B * nblk
+    g = torch.Generator(device=DEV).manual_seed(0)
+    kc = torch.randn(nb, bs, Hkv, D, generator=g, device=DEV, dtype=torch.float32).to(dtype)
+    vc = torch.randn(nb, bs, Hkv, D, generator=g, device=DEV, dtype=torch.float32).to(dtype)
+    q = torch.randn(B, Hq, D, generator=g, device=DEV, dtype=torch.float32).to(dtype)
+    table = torch.arange(nb, dtype=torch.int32, device=DEV).view(B, nblk)
+    ctx = torch.full((B,), ctxlen, dtype=torch.int32, device=DEV)
+    ctx[::7] = 1000
+    out1 = H.paged_decode(q, kc, vc, table, ctx, D ** -0.5)
+    perm = torch.randperm(nb, generator=torch.Generator().manual_seed(1)).to(DEV)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(nb, device=DEV)
+    kc2, vc2 = kc[perm], vc[perm]                  # new block j holds old block perm[j]
+    table2 = inv[table.long()].to(torch.int32)     # old id -> new id
+    out2 = H.paged_decode(q, kc2, vc2, table2, ctx, D ** -0.5)
+    assert torch.equal(out1, out2)
+    # and a sampled subset against the oracle
+    rows = [0, 7, 100, 255]
+    ref = O.paged_decode(q[rows].cpu(), kc.cpu(), vc.cpu(), table[rows].cpu(), ctx[rows].cpu(), D ** -0.5)
+    torch.testing.assert_close(out1[rows].float().cpu(), ref, **_tol(dtype))
+
+
+# ------------------------------------------------------------------ K6
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize("cols", [128, 1024, 2048, 3584, 8192])
+def test_rmsnorm_and_add(H, dtype, cols):
+    rows = 19
+    x = _randn(rows, cols, dtype=dtype, seed=1)
+    r = _randn(rows, cols, dtype=dtype, seed=2)
+    w = (1.0 + 0.1 * _randn(cols, dtype=torch.float32, seed=3)).to(dtype)
+    eps = 1e-6
+    y_ref = O.rmsnorm(x, w, eps)
+    y = H.rmsnorm(x.to(DEV), w.to(DEV), eps)
+    # single rounding of an fp32 result: at most 1 ulp of the output dtype
+    ulp = {torch.bfloat16: 2 ** -7, torch.float16: 2 ** -10, torch.float32: 1e-5}[dtype]
+    torch.testing.assert_close(y.float().cpu(), y_ref.float(), rtol=ulp, atol=ulp * 1e-2)
+    y2_ref, res_ref = O.add_rmsnorm(x, r, w, eps)
+    rd = r.to(DEV)
+    y2, res = H.add_rmsnorm(x.to(DEV), rd, w.to(DEV), eps, inplace=True)
+    assert res.data_ptr() == rd.data_ptr()
+    assert torch.equal(res.cpu(), res_ref)  # the residual is an exactly rounded fp32 sum
+    torch.testing.assert_close(y2.float().cpu(), y2_ref.float(), rtol=ulp, atol=ulp * 1e-2)
+    if dtype != torch.float32:
+        frac_exact = (y.cpu() == y_ref).float().mean().item()
+        assert frac_exact > 0.99  # bit-exact but for reduction-order flips
+
+
+def test_rmsnorm_strided_rows_and_3d(H):
+    big = _randn(10, 4096, dtype=torch.bfloat16, seed=5).to(DEV)
+    x = big[:, 1024:3072]  # row-strided view
+    w = torch.ones(2048, dtype=torch.bfloat16, device=DEV)
+    y = H.rmsnorm(x, w, 1e-6)
+    torch.testing.assert_close(y.float().cpu(), O.rmsnorm(x.cpu(), w.cpu(), 1e-6).float(), rtol=2 ** -7, atol=1e-4)
+    x3 = _randn(6, 8, 128, dtype=torch.bfloat16, seed=6).to(DEV)  # per-head norm shape
+    w3 = torch.ones(128, dtype=torch.bfloat16, device=DEV)
+    y3 = H.rmsnorm(x3, w3, 1e-6)
+    assert y3.shape == x3.shape
+    torch.testing.assert_close(y3.float().cpu(), O.rmsnorm(x3.cpu(), w3.cpu(), 1e-6).float(), rtol=2 ** -7, atol=1e-4)
+
+
+# ------------------------------------------------------------------ K9
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_silu_and_mul(H, dtype):
+    x = _randn(33, 2 * 6144, dtype=dtype, seed=8)
+    ref = O.silu_and_mul(x)
+    out = H.silu_and_mul(x.to(DEV))
+    ulp = {torch.bfloat16: 2 ** -7, torch.float32: 1e-5}[dtype]
+    torch.testing.assert_close(out.float().cpu(), ref.float(), rtol=2 * ulp, atol=1e-6)
+    with pytest.raises(ValueError):
+        H.silu_and_mul(torch.zeros(2, 7, device=DEV))
+
+
+# ------------------------------------------------------------------ K7
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("qk_norm", [True, False])
+@pytest.mark.parametrize("D", [128, 64])
+def test_rope_qk_store(H, dtype, qk_norm, D):
+    T, Hq, Hkv, nb, bs, max_pos = 45, 8, 4, 3, 64, 4096
+    qkv = _randn(T, (Hq + 2 * Hkv) * D, dtype=dtype, seed=20)
+    q = qkv[:, :Hq * D].view(T, Hq, D)
+    k = qkv[:, Hq * D:(Hq + Hkv) * D].view(T, Hkv, D)
+    v = qkv[:, (Hq + Hkv) * D:].view(T, Hkv, D)
+    pos = torch.randint(0, max_pos, (T,), generator=torch.Generator().manual_seed(21))
+    pos[0], pos[1] = 0, max_pos - 1
+    cos, sin = O.rope_tables(D, max_pos, 1e6 if not qk_norm else 1e4)
+    qw = (1 + 0.1 * _randn(D, dtype=torch.float32, seed=22)).to(dtype) if qk_norm else None
+    kw = (1 + 0.1 * _randn(D, dtype=torch.float32, seed=23)).to(dtype) if qk_norm else None
+    slots = torch.randperm(nb * bs, generator=torch.Generator().manual_seed(24))[:T].to(torch.int32)
+    slots[5] = -1
+    kc_ref = torch.zeros(nb, bs, Hkv, D, dtype=dtype)
+    vc_ref = torch.zeros_like(kc_ref)
+    q_ref, k_ref = O.rope_qk_store(q, k, v, pos, cos, sin, qw, kw, 1e-6, kc_ref, vc_ref, slots)
+    d = lambda t: None if t is None else t.to(DEV)
+    qkv_d = qkv.to(DEV)
+    qd = qkv_d[:, :Hq * D].view(T, Hq, D)
+    kd = qkv_d[:, Hq * D:(Hq + Hkv) * D].view(T, Hkv, D)
+    vd = qkv_d[:, (Hq + Hkv) * D:].view(T, Hkv, D)
+    kc, vc = torch.zeros_like(kc_ref).to(DEV), torch.zeros_like(vc_ref).to(DEV)
+    q_out, k_out = H.rope_qk_store(qd, kd, vd, d(pos), d(cos), d(sin), d(qw), d(kw), 1e-6, kc, vc, d(slots))
+    tol = dict(rtol=2 ** -7, atol=2 ** -7) if dtype == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(q_out.float().cpu(), q_ref.float(), **tol)
+    torch.testing.assert_close(k_out.float().cpu(), k_ref.float(), **tol)
+    assert torch.equal(vc.cpu(), vc_ref)                 # V rows are a byte copy
+    assert torch.equal(kc.cpu().view(-1, Hkv, D)[slots[slots >= 0].long()], k_out.cpu()[slots >= 0])
+    if not qk_norm:  # pure elementwise path restates the reference's rounding points: bit-exact
+        assert torch.equal(q_out.cpu(), q_ref) and torch.equal(k_out.cpu(), k_ref)
+    # no cache / no k_out variants
+    q2, k2 = H.rope_qk_store(qd, kd, None, d(pos), d(cos), d(sin), d(qw), d(kw), 1e-6, want_k_out=False)
+    assert k2 is None and torch.equal(q2, q_out)
+
+
+# ------------------------------------------------------------------ K2
+PREFILL_CASES = [
+    # Hq, Hkv, D, seqlens
+    (4, 2, 128, [5, 130, 64, 1]),
+    (7, 1, 128, [200, 33]),
+    (4, 4, 64, [17, 90]),
+    (16, 8, 128, [257]),
+]
+
+
+@pytest.mark.parametrize("case", PREFILL_CASES, ids=[f"case{i}" for i in range(len(PREFILL_CASES))])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_prefill_varlen_vs_oracle(H, case, dtype):
+    Hq, Hkv, D, lens = case
+    T = sum(lens)
+    q = _randn(T, Hq, D, dtype=dtype, seed=30)
+    k = _randn(T, Hkv, D, dtype=dtype, seed=31)
+    v = _randn(T, Hkv, D, dtype=dtype, seed=32)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    scale = D ** -0.5
+    ref = O.prefill_varlen(q, k, v, cu, cu, scale)
+    out = H.prefill_varlen(q.to(DEV), k.to(DEV), v.to(DEV), cu.to(DEV), cu.to(DEV), max(lens), max(lens), scale)
+    torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_prefill_paged_prefix(H, dtype):
+    """Prefix-cache hit: queries are the uncached suffix, keys come from the paged cache
+    (flash-attn semantics; oracle = full no-cache prefill rows)."""
+    Hq, Hkv, D, bs = 8, 4, 128, 64
+    full = [64 + 5, 128 + 64, 40]       # total lengths
+    cached = [64, 128, 0]               # cached prefix (multiples of bs)
+    B = len(full)
+    kc, vc, table = _make_paged(B, Hkv, D, bs, full, dtype, seed=40)
+    qs = [f - c for f, c in zip(full, cached)]
+    q_full = _randn(sum(full), Hq, D, dtype=dtype, seed=41)
+    cu_k = torch.tensor([0] + list(torch.tensor(full).cumsum(0)), dtype=torch.int32)
+    cu_q = torch.tensor([0] + list(torch.tensor(qs).cumsum(0)), dtype=torch.int32)
+    kk, vv = O.gather_paged_kv(kc, vc, table, full)
+    ref_full = O.prefill_varlen(q_full, kk, vv, cu_k, cu_k, D ** -0.5)
+    sel = torch.cat([torch.arange(int(cu_k[i]) + cached[i], int(cu_k[i + 1])) for i in range(B)])
+    out = H.prefill_varlen(q_full[sel].to(DEV), None, None, cu_q.to(DEV), cu_k.to(DEV), max(qs), max(full),
+                           D ** -0.5, k_cache=kc.to(DEV), v_cache=vc.to(DEV), block_tables=table.to(DEV))
+    torch.testing.assert_close(out.float().cpu(), ref_full[sel], **_tol(dtype))
+
+
+# ------------------------------------------------------------------ K8
+def _sampler_inputs(B, V, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    # well separated values: a random permutation of a fine grid (no ties, exact in bf16 for small V)
+    base = torch.stack([torch.randperm(V, generator=g).float() for _ in range(B)])
+    logits = (base - V / 2) * (8.0 / V)
+    return logits.to(dtype)
+
+
+@pytest.mark.parametrize("V", [50, 1000, 50272])
+def test_sampler_support_sets_fp32(H, V):
+    B = 8
+    logits = _sampler_inputs(B, V, torch.float32, seed=50)
+    temps = torch.tensor([1.0, 0.6, 0.6, 1.5, 0.0, 1.0, 0.8, 1.0])
+    top_ks = torch.tensor([-1, 40, -1, 5, 3, V + 5, 40, 1], dtype=torch.int64)
+    top_ps = torch.tensor([1.0, 0.95, 0.9, 1.0, 0.5, 0.7, 0.95, 1.0])
+    min_ps = torch.tensor([0.0, 0.0, 0.0, 0.0, 0.0, 0.05, 0.1, 0.0])
+    keep_ref, _ = O.sampler_keep_mask(logits, temps, top_ks, top_ps, min_ps)
+    d = lambda t: t.to(DEV)
+    toks, mask = H.sample(d(logits), d(temps), d(top_ks), d(top_ps), d(min_ps), seed=1, offset=0, return_mask=True)
+    mask = mask.bool().cpu()
+    for b in range(B):
+        diff = (mask[b] != keep_ref[b]).sum().item()
+        # fp32 cumulative sums in a different order may move the nucleus edge by one token
+        assert diff <= 1, f"row {b}: support differs in {diff} tokens"
+        assert mask[b, toks[b]].item(), f"row {b}: sampled a filtered token"
+    assert toks[4].item() == int(torch.argmax(logits[4]))  # temperature 0 -> argmax
+    assert toks[7].item() == int(torch.argmax(logits[7]))  # top_k = 1
+
+
+def test_sampler_bf16_and_ties(H):
+    V = 151936
+    g = torch.Generator().manual_seed(3)
+    logits = (torch.randn(4, V, generator=g) * 2).to(torch.bfloat16)
+    temps = torch.tensor([0.6, 1.0, 0.0, 0.7])
+    top_ks = torch.tensor([40, 1000, -1, -1], dtype=torch.int64)
+    top_ps = torch.tensor([0.95, 1.0, 1.0, 0.9])
+    min_ps = torch.zeros(4)
+    d = lambda t: t.to(DEV)
+    toks, mask = H.sample(d(logits), d(temps), d(top_ks), d(top_ps), d(min_ps), seed=7, return_mask=True)
+    mask = mask.bool().cpu()
+    assert mask[0].sum().item() <= 40 and mask[1].sum().item() == 1000  # exactly k survive ties
+    # every kept logit >= every dropped logit (a top set by value)
+    for b in (0, 1, 3):
+        assert logits[b][mask[b]].float().min() >= logits[b][~mask[b]].float().max()
+    assert toks[2].item() == int(torch.argmax(logits[2].float()))
+    # nucleus mass of row 3 reaches p, and dropping its smallest kept value group would fall below p
+    probs = torch.softmax(logits[3].float() / 0.7, -1)
+    assert probs[mask[3]].sum().item() >= 0.9 - 1e-3
+
+
+def test_sampler_distribution_chi2(H):
+    """Multinomial draw: 20000 draws of one row against the oracle's distribution."""
+    V, N = 64, 20000
+    logits = _sampler_inputs(1, V, torch.float32, seed=60).repeat(N, 1)
+    temps = torch.full((N,), 0.9)
+    top_ks = torch.full((N,), 20, dtype=torch.int64)
+    top_ps = torch.full((N,), 0.9)
+    min_ps = torch.zeros(N)
+    d = lambda t: t.to(DEV)
+    toks = H.sample(d(logits), d(temps), d(top_ks), d(top_ps), d(min_ps), seed=123, offset=5).cpu()
+    probs = O.sampler_probs(logits[:1], temps[:1], top_ks[:1], top_ps[:1], min_ps[:1])[0]
+    counts = torch.bincount(toks, minlength=V).float()
+    assert counts[probs == 0].sum().item() == 0
+    sup = probs > 0
+    chi2 = (((counts[sup] - N * probs[sup]) ** 2) / (N * probs[sup])).sum().item()
+    dof = int(sup.sum()) - 1
+    assert chi2 < dof + 6 * math.sqrt(2 * dof), (chi2, dof)
+    # different offset -> different stream; same (seed, offset) -> identical draws
+    t2 = H.sample(d(logits), d(temps), d(top_ks), d(top_ps), d(min_ps), seed=123, offset=5).cpu()
+    t3 = H.sample(d(logits), d(temps), d(top_ks), d(top_ps), d(min_ps), seed=123, offset=6).cpu()
+    assert torch.equal(toks, t2) and not torch.equal(toks, t3)
+
+
+def test_sampler_degenerate_rows(H):
+    V = 1000
+    logits = torch.full((2, V), float("-inf"))
+    logits[1, 7] = 3.0
+    d = lambda t: t.to(DEV)
+    toks = H.sample(d(logits), d(torch.ones(2)), d(torch.tensor([-1, -1])), d(torch.ones(2)), d(torch.zeros(2)), seed=1)
+    assert 0 <= toks[0].item() < V   # all filtered -> uniform fallback (functional.py:419-429)
+    assert toks[1].item() == 7
