@@ -1,0 +1,107 @@
+"""Two-phase FIFO batch scheduler (mirror of minivllm/engine/scheduler.py:55-293):
+prefill has priority and packs whole prompts up to max_num_seqs / max_num_batched_tokens;
+otherwise every running sequence decodes one token, preempting the newest when blocks run
+out.  Preempted sequences lose their blocks and are re-prefilled from the front of the queue
+(recompute; the prefix cache often rescues them)."""
+from __future__ import annotations
+
+import logging
+from collections import deque
+
+from ..config import Config
+from .block_manager import BlockManager
+from .sequence import Sequence, SequenceStatus
+
+__all__ = ["Scheduler"]
+logger = logging.getLogger(__name__)
+
+
+class Scheduler:
+    def __init__(self, config: Config) -> None:
+        self.max_num_seqs = config.max_num_seqs
+        self.max_num_batched_tokens = config.max_num_batched_tokens
+        self.eos = config.eos
+        self.block_manager = BlockManager(config.num_kvcache_blocks, config.kvcache_block_size)
+        self.waiting: deque[Sequence] = deque()
+        self.running: deque[Sequence] = deque()
+
+    def is_finished(self) -> bool:
+        return not self.waiting and not self.running
+
+    def add(self, sequence: Sequence) -> None:
+        self.waiting.append(sequence)
+
+    def schedule(self) -> tuple[list[Sequence], bool]:
+        if self.is_finished():
+            raise RuntimeError("No sequences scheduled")
+        batch = self._schedule_prefill()
+        if batch:
+            return batch, True
+        batch = self._schedule_decode()
+        if batch:
+            return batch, False
+        if not self.is_finished():
+            msg = (f"No sequences scheduled, but scheduler is not finished. State: "
+                   f"waiting={len(self.waiting)}, running={len(self.running)}, "
+                   f"max_num_seqs={self.max_num_seqs}, max_num_batched_tokens={self.max_num_batched_tokens}")
+            if self.waiting:
+                msg += f", first_waiting_seq_len={len(self.waiting[0])}"
+            if self.running:
+                msg += f", running_seq_lens={[len(s) for s in list(self.running)[:5]]}"
+            raise RuntimeError(msg)
+        return [], False
+
+    def _schedule_prefill(self) -> list[Sequence]:
+        batch: list[Sequence] = []
+        tokens = 0
+        while self.waiting and len(batch) < self.max_num_seqs:
+            seq = self.waiting[0]
+            # the budget test uses the full length; the charge below only the uncached part
+            if tokens + len(seq) > self.max_num_batched_tokens or not self.block_manager.can_allocate(seq):
+                break
+            self.block_manager.allocate(seq)
+            tokens += len(seq) - seq.num_cached_tokens
+            seq.status = SequenceStatus.RUNNING
+            self.waiting.popleft()
+            self.running.append(seq)
+            batch.append(seq)
+        return batch
+
+    def _can_step(self, seq: Sequence) -> bool:
+        bm = self.block_manager
+        if not bm.can_append(seq):
+            return False
+        # beyond the reference: never walk into may_append's "No free blocks available"
+        return not (bm.needs_block_now(seq) and bm.get_num_free_blocks() == 0)
+
+    def _schedule_decode(self) -> list[Sequence]:
+        batch: list[Sequence] = []
+        while self.running and len(batch) < self.max_num_seqs:
+            seq = self.running.popleft()
+            while not self._can_step(seq):
+                if self.running:
+                    self.preempt(self.running.pop())  # newest first
+                else:
+                    self.preempt(seq)
+                    break
+            else:
+                self.block_manager.may_append(seq)
+                batch.append(seq)
+        if batch:
+            self.running.extendleft(reversed(batch))
+        return batch
+
+    def preempt(self, sequence: Sequence) -> None:
+        logger.info("Preempting sequence %d due to memory constraints.", sequence.seq_id)
+        sequence.status = SequenceStatus.WAITING
+        self.block_manager.deallocate(sequence)
+        self.waiting.appendleft(sequence)
+
+    def postprocess(self, sequences: list[Sequence], token_ids: list[int]) -> None:
+        for seq, token in zip(sequences, token_ids, strict=True):
+            seq.append_token(token)
+            hit_eos = token == self.eos and not seq.ignore_eos
+            if hit_eos or seq.num_completion_tokens >= seq.max_tokens:
+                seq.status = SequenceStatus.FINISHED
+                self.block_manager.deallocate(seq)
+                self.running.remove(seq)

@@ -1,0 +1,229 @@
+"""Host-side integer logic (block manager, scheduler, sequence, input builder) replayed against
+traces recorded from the reference (tests/golden/host_traces.json, tools/gen_goldens.py):
+block tables, slot mappings, cu_seqlens, positions, context lens, batch composition, preemption
+order, prefix-cache counters and xxh64 digests must match BIT FOR BIT, dtypes included."""
+import json
+import os
+import pickle
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from minivllm_amd.engine.block_manager import BlockManager
+from minivllm_amd.engine.input_builder import InputBuilder
+from minivllm_amd.engine.scheduler import Scheduler
+from minivllm_amd.engine.sequence import Sequence, SequenceStatus
+from minivllm_amd.sampling_params import SamplingParams
+
+
+@pytest.fixture(scope="module")
+def traces(golden_dir):
+    with open(os.path.join(golden_dir, "host_traces.json")) as f:
+        return json.load(f)
+
+
+def fake_next_token(tokens, vocab):
+    return (sum(tokens) * 31 + len(tokens) * 7 + 3) % vocab
+
+
+def test_xxh64_digests(traces):
+    for case in traces["hashes"]:
+        assert BlockManager.compute_hash(case["tokens"], case["prefix"]) == case["hash"]
+    # SURVEY §8 known answers
+    assert BlockManager.compute_hash([1, 2, 3]) == 13048208712247349756
+    assert BlockManager.compute_hash([1, 2, 3], prefix=5) == 17518828517520909647
+    assert BlockManager.compute_hash(list(range(64))) == 4138455281752509893
+    with pytest.raises(ValueError):
+        BlockManager.compute_hash([])
+
+
+def _check_tensor(name, got, want, want_dtype, step):
+    if want is None:
+        assert got is None, f"step {step}: {name} should be None"
+        return
+    assert got is not None, f"step {step}: {name} missing"
+    assert str(got.dtype).replace("torch.", "") == want_dtype, f"step {step}: {name} dtype {got.dtype}"
+    assert got.tolist() == want, f"step {step}: {name} differs"
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_replay_reference_trace(traces, idx):
+    rec = traces["scenarios"][idx]
+    sc = rec["scenario"]
+    cfg = SimpleNamespace(max_num_seqs=sc["max_num_seqs"], max_num_batched_tokens=sc["max_num_batched_tokens"],
+                          eos=sc.get("eos", -1), num_kvcache_blocks=sc["num_blocks"],
+                          kvcache_block_size=sc["block_size"])
+    sched = Scheduler(cfg)
+    builder = InputBuilder(sc["block_size"], sc["max_num_seqs"], sc["max_model_len"], sc["max_num_batched_tokens"])
+    seqs = [Sequence(r["tokens"], SamplingParams(temperature=r.get("temperature", 1.0), max_tokens=r["max_tokens"],
+                                                 ignore_eos=r.get("ignore_eos", False)), block_size=sc["block_size"])
+            for r in sc["requests"]]
+    index_of = {id(s): i for i, s in enumerate(seqs)}
+    add_at = sc.get("add_at", [0] * len(seqs))
+    pending = list(range(len(seqs)))
+    step_no, k = 0, 0
+    while True:
+        for i in list(pending):
+            if add_at[i] <= step_no:
+                sched.add(seqs[i])
+                pending.remove(i)
+        if sched.is_finished() and not pending:
+            break
+        if sched.is_finished():
+            step_no += 1
+            continue
+        want = rec["steps"][k]
+        batch, is_prefill = sched.schedule()
+        assert is_prefill == want["is_prefill"], f"step {k}"
+        assert [index_of[id(s)] for s in batch] == want["seq_index"], f"step {k}: batch composition"
+        assert [list(s.block_table) for s in batch] == want["block_table_per_seq"], f"step {k}: block ids"
+        assert [s.num_cached_tokens for s in batch] == want["num_cached_tokens"], f"step {k}"
+        inp = builder.prefill(batch) if is_prefill else builder.decode(batch)
+        assert (inp.max_seqlen_q, inp.max_seqlen_k) == (want["max_seqlen_q"], want["max_seqlen_k"])
+        _check_tensor("input_ids", inp.input_ids, want["input_ids"], want["input_ids_dtype"], k)
+        _check_tensor("positions", inp.positions, want["positions"], want["positions_dtype"], k)
+        for name in ("cum_seqlens_q", "cum_seqlens_k", "slot_mapping", "context_lens", "block_tables"):
+            _check_tensor(name, getattr(inp, name), want[name], want[name + "_dtype"], k)
+        toks = [fake_next_token(s.token_ids, sc["vocab"]) for s in batch]
+        assert toks == want["next_tokens"]
+        sched.postprocess(batch, toks)
+        assert [s.is_finished for s in batch] == want["finished"], f"step {k}"
+        assert sched.block_manager.get_num_free_blocks() == want["free_blocks_after"], f"step {k}"
+        assert [index_of[id(s)] for s in sched.waiting] == want["waiting_after"], f"step {k}"
+        assert [index_of[id(s)] for s in sched.running] == want["running_after"], f"step {k}"
+        k += 1
+        step_no += 1
+    assert k == len(rec["steps"])
+    assert [dict(tokens=s.token_ids, num_completion=s.num_completion_tokens) for s in seqs] == rec["final"]
+    assert sched.block_manager.stats == rec["stats"]
+
+
+def test_survey_known_answer_trace():
+    """two prompts (130 and 3 tokens), fresh BlockManager(16, 64)."""
+    bm = BlockManager(16, 64)
+    a, b = Sequence(list(range(1, 131))), Sequence(list(range(500, 503)))
+    bm.allocate(a)
+    bm.allocate(b)
+    ib = InputBuilder(64, 8, 1024, 4096)
+    p = ib.prefill([a, b])
+    assert p.cum_seqlens_q.tolist() == p.cum_seqlens_k.tolist() == [0, 130, 133]
+    assert p.slot_mapping.tolist() == list(range(130)) + [192, 193, 194]
+    assert p.block_tables.tolist() == [[0, 1, 2], [3, -1, -1]] and p.context_lens is None
+    for s in (a, b):
+        s.append_token(7)
+        bm.may_append(s)
+    d = ib.decode([a, b])
+    assert d.slot_mapping.tolist() == [130, 195] and d.context_lens.tolist() == [131, 4]
+    assert d.positions.tolist() == [130, 3] and d.block_tables.tolist() == [[0, 1, 2], [3, -1, -1]]
+    assert (d.max_seqlen_q, d.max_seqlen_k, d.cum_seqlens_q) == (0, 0, None)
+
+
+def test_prefix_cache_hit_shares_block():
+    bm = BlockManager(8, 64)
+    a = Sequence(list(range(1, 65)) + [200, 201, 202])
+    b = Sequence(list(range(1, 65)) + [300, 301, 302, 303, 304])
+    bm.allocate(a)
+    bm.allocate(b)
+    assert (a.block_table, b.block_table, b.num_cached_tokens) == ([0, 1], [0, 2], 64)
+    assert bm.blocks[0].ref_count == 2 and bm.stats["cache_hits"] == 1
+    bm.deallocate(a)
+    assert bm.blocks[0].ref_count == 1 and 0 in bm.used_block_ids
+    bm.deallocate(b)
+    c = Sequence(list(range(1, 65)) + [9])      # block 0 is free but still cached: revived, not reset
+    bm.allocate(c)
+    assert c.block_table[0] == 0 and c.num_cached_tokens == 64
+
+
+def test_fully_cached_prompt_keeps_a_query_block():
+    """Build semantics where the reference is broken: a prompt whose every block
+    hits the prefix cache recomputes its last block so that a last-token logit exists."""
+    bm = BlockManager(8, 64)
+    toks = list(range(1, 129))
+    a, b = Sequence(toks), Sequence(toks)
+    bm.allocate(a)
+    bm.allocate(b)
+    assert b.block_table == a.block_table and b.num_cached_tokens == 64
+    p = InputBuilder(64, 4, 512, 1024).prefill([b])
+    assert p.cum_seqlens_q.tolist() == [0, 64] and p.cum_seqlens_k.tolist() == [0, 128]
+    assert p.positions.tolist() == list(range(64, 128))
+    assert p.slot_mapping.tolist() == list(range(b.block_table[1] * 64, b.block_table[1] * 64 + 64))
+
+
+def test_block_pressure_preempts_instead_of_raising():
+    """the reference raises 'No free blocks available' when a sequence needs its
+    next block (len % bs == 1) and none is free; the build preempts the newest sequence instead."""
+    cfg = SimpleNamespace(max_num_seqs=4, max_num_batched_tokens=512, eos=-1, num_kvcache_blocks=3,
+                          kvcache_block_size=64)
+    sched = Scheduler(cfg)
+    a = Sequence(list(range(1, 65)), SamplingParams(max_tokens=40, ignore_eos=True))
+    b = Sequence(list(range(100, 164)), SamplingParams(max_tokens=40, ignore_eos=True))
+    sched.add(a)
+    sched.add(b)
+    steps = 0
+    while not sched.is_finished():
+        batch, _ = sched.schedule()
+        sched.postprocess(batch, [1] * len(batch))
+        steps += 1
+        assert steps < 400
+    assert a.num_completion_tokens == 40 and b.num_completion_tokens == 40
+
+
+def test_sequence_block_math_and_pickle():
+    s = Sequence(list(range(130)), SamplingParams(temperature=0.5, top_k=7, max_tokens=9), block_size=64)
+    assert (s.num_blocks, s.last_block_num_tokens, s.num_cached_blocks) == (3, 2, 0)
+    assert s.block(2) == [128, 129] and len(s.block(0)) == 64
+    with pytest.raises(IndexError):
+        s.block(3)
+    with pytest.raises(ValueError):
+        Sequence([])
+    with pytest.raises(ValueError):
+        s.append_token(-1)
+    r = pickle.loads(pickle.dumps(s))            # prompt phase: whole prompt travels
+    assert r.token_ids == s.token_ids and r.status == SequenceStatus.WAITING and r.top_k == 7
+    s.append_token(5)
+    s.block_table = [4, 2, 9]
+    r = pickle.loads(pickle.dumps(s))            # decode phase: only the last token travels
+    assert r.last_token == 5 and len(r) == 131 and r.token_ids[-1] == 5 and r.token_ids[0] == 0
+    assert r.block_table == [4, 2, 9] and r.status == SequenceStatus.RUNNING
+    s.status = SequenceStatus.FINISHED
+    with pytest.raises(RuntimeError):
+        s.append_token(1)
+
+
+def test_sampling_params_validation():
+    SamplingParams(temperature=0.0)
+    for bad in (dict(temperature=-0.1), dict(top_p=0.0), dict(top_p=1.5), dict(top_k=0), dict(top_k=-2),
+                dict(min_p=1.5), dict(max_tokens=0)):
+        with pytest.raises(ValueError):
+            SamplingParams(**bad)
+
+
+def test_block_manager_errors_and_may_append_boundaries():
+    with pytest.raises(ValueError):
+        BlockManager(0, 64)
+    with pytest.raises(ValueError):
+        BlockManager(4, 0)
+    bm = BlockManager(2, 4)
+    s = Sequence([1, 2, 3], block_size=4)
+    bm.allocate(s)
+    with pytest.raises(ValueError):
+        bm.allocate(s)                              # already has blocks
+    assert bm.blocks[s.block_table[0]].hash == -1   # partial block: no digest
+    s.append_token(4)
+    bm.may_append(s)                                # block filled: digest published
+    blk = bm.blocks[s.block_table[0]]
+    assert blk.hash == BlockManager.compute_hash([1, 2, 3, 4]) and bm.hash_to_block_id[blk.hash] == blk.block_id
+    s.append_token(5)
+    bm.may_append(s)                                # first token of a new block: block taken
+    assert len(s.block_table) == 2 and bm.get_num_free_blocks() == 0
+    big = Sequence(list(range(20)), block_size=4)
+    assert not bm.can_allocate(big)
+    with pytest.raises(ValueError):
+        bm.allocate(big)
+    bm.deallocate(s)
+    assert bm.get_num_free_blocks() == 2 and s.block_table == [] and s.num_cached_tokens == 0
+    # digest is dropped when the block is handed out for new content
+    t = Sequence([9, 9, 9, 9, 9], block_size=4)
+    bm.allocate(t)
+    assert blk.hash != BlockManager.compute_hash([1, 2, 3, 4]) or blk.block_id not in t.block_table

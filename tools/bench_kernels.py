@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the libmvhip.so kernels (HIP-event timed, algorithmic GB/s)."""
+import argparse
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from minivllm_amd import hip_ops as H
+
+DEV = "cuda:0"
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def bench_decode(B, Hq, Hkv, D, ctx, bs=64, dtype=torch.bfloat16, layers=4):
+    nblk = (ctx + bs - 1) // bs
+    nb = B * nblk
+    # several "layers" of cache so that successive launches do not hit in the 256 MiB Infinity Cache
+    caches = [(torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.float32).to(dtype),
+               torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.float32).to(dtype)) for _ in range(layers)]
+    q = torch.randn(B, Hq, D, device=DEV).to(dtype)
+    table = torch.randperm(nb, device=DEV).to(torch.int32).view(B, nblk)
+    cl = torch.full((B,), ctx, dtype=torch.int32, device=DEV)
+    out = torch.empty_like(q)
+    state = {"i": 0}
+
+    def fn():
+        k, v = caches[state["i"] % layers]
+        state["i"] += 1
+        H.paged_decode(q, k, v, table, cl, D ** -0.5, out=out)
+    t = timeit(fn)
+    esz = 2 if dtype != torch.float32 else 4
+    bytes_ = B * ctx * 2 * Hkv * D * esz + 2 * B * Hq * D * esz + B * nblk * 4
+    print(f"paged_decode B={B} H={Hq}/{Hkv} D={D} ctx={ctx}: {t*1e6:8.1f} us  {bytes_/t/1e9:8.1f} GB/s  ({bytes_/1e6:.1f} MB)")
+    return t, bytes_
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    a = ap.parse_args()
+    print(torch.cuda.get_device_name(0))
+    bench_decode(256, 16, 8, 128, 1024)          # Qwen3-1.7B headline
+    if not a.quick:
+        bench_decode(256, 16, 8, 128, 4096, layers=2)
+        bench_decode(256, 28, 4, 128, 1024)      # Qwen2-7B
+        bench_decode(256, 8, 1, 128, 1024)       # 72B @ TP8
+        bench_decode(64, 16, 8, 128, 1024)
+        bench_decode(8, 16, 8, 128, 1024)
+        bench_decode(1, 16, 8, 128, 4096)
+        bench_decode(8, 28, 4, 128, 4096)

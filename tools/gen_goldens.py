@@ -193,11 +193,13 @@ def host_traces(tmp):
                        dict(tokens=list(range(500, 503)), max_tokens=3, ignore_eos=True)]),
         # prefix-cache hits: shared 128-token prefix, staggered arrival, boundary-length prompts
         dict(name="prefix_cache", num_blocks=24, block_size=64, max_model_len=1024,
-             max_num_batched_tokens=4096, max_num_seqs=8, vocab=320, add_at=[0, 0, 3, 6, 6],
+             max_num_batched_tokens=4096, max_num_seqs=8, vocab=320, add_at=[0, 0, 3, 6],
              requests=[dict(tokens=shared + rnd(5), max_tokens=6, ignore_eos=True),
                        dict(tokens=shared + rnd(70), max_tokens=4, ignore_eos=True),
                        dict(tokens=shared[:64] + rnd(64), max_tokens=5, ignore_eos=True),
-                       dict(tokens=shared, max_tokens=3, ignore_eos=True),         # fully cached prompt (len%64==0)
+                       # (a fully cached prompt, len % 64 == 0 with every block hit, is NOT pinned: the
+                       #  reference then prefills zero query tokens — SURVEY §9 Q3 — the build recomputes
+                       #  the last block instead; covered by tests/test_host_logic.py)
                        dict(tokens=rnd(63), max_tokens=70, ignore_eos=True)]),      # crosses a block while decoding
         # memory pressure: preemption of the newest sequence, re-prefill, FIFO order.  (Parameters found
         # by search: under block pressure the reference often raises "No free blocks available"
