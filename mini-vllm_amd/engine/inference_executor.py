@@ -1,0 +1,351 @@
+"""Batch execution on one GPU: KV-cache sizing/allocation, input shipping, eager or hipGraph
+model execution, sampling (mirror of minivllm/engine/inference_executor.py:35-943).
+
+MI355X-first differences from the reference:
+  * KV cache sized for 288 GB HBM3E with the LOCAL kv-head count (the reference uses the total
+    head count even under TP) — layout [2, L, num_blocks, block_size, Hkv/tp, D];
+  * the decode step — model forward, LM head AND the sampler — is ONE captured hipGraph per
+    batch-size bucket; every per-step quantity (ids, positions, slots, context lens, block
+    tables, sampling params, RNG offset) lives in static device buffers that are refreshed by
+    a handful of async copies; the only host sync of a step is reading back the B token ids;
+  * the reference's graph path is dead code (row-0 broadcast bug, fp32 output buffer, host syncs
+    in the attention fallback: SURVEY §9 Q2); here graph replay is checked bit-identical
+    against eager execution.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+import torch
+
+from ..config import Config
+from ..layers.sampler import Sampler
+from ..parallel_state import get_tensor_parallel_world_size
+from ..utils.context import reset_context, set_context
+from .. import hip_ops
+from .input_builder import BatchInputs, InputBuilder
+from .model_manager import resolve_dtype
+from .sequence import Sequence
+
+logger = logging.getLogger(__name__)
+__all__ = ["InferenceExecutor", "graph_batch_sizes", "kv_block_bytes"]
+
+
+def graph_batch_sizes(max_batch_size: int) -> list[int]:
+    """Decode graph buckets: 1,2,4,8,12 then every 16 up to min(max, 512)
+    (inference_executor.py:839-841)."""
+    sizes = [1, 2, 4, 8, 12] + list(range(16, min(max_batch_size, 512) + 1, 16))
+    return [s for s in sizes if s <= max(max_batch_size, 1)] or [1]
+
+
+def kv_block_bytes(num_layers: int, block_size: int, num_kv_heads_local: int, head_dim: int, itemsize: int) -> int:
+    return 2 * num_layers * block_size * num_kv_heads_local * head_dim * itemsize
+
+
+class InferenceExecutor:
+    def __init__(self, config: Config, model, device: torch.device | None = None) -> None:
+        self.config = config
+        self.model = model
+        self.device = device if device is not None else next(model.parameters()).device
+        self.block_size = config.kvcache_block_size
+        hf = config.hf_config
+        tp = get_tensor_parallel_world_size()
+        total_kv = getattr(hf, "num_key_value_heads", getattr(hf, "num_attention_heads", 1))
+        self.num_kv_heads = max(total_kv // tp, 1)
+        self.head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
+        self.num_layers = hf.num_hidden_layers
+        try:
+            self.dtype = next(model.parameters()).dtype
+        except (StopIteration, AttributeError):
+            self.dtype = resolve_dtype(config)
+        self.enforce_eager = config.enforce_eager
+        self.kv_cache: torch.Tensor | None = None
+        self.sampler: Sampler | None = None
+        self.graphs: dict[int, torch.cuda.CUDAGraph] = {}
+        self.graph_bs: list[int] = []
+        self.graph_vars: dict[str, torch.Tensor] = {}
+        self.graph_pool = None
+        self.total_tokens_generated = self.total_prefill_tokens = self.total_decode_tokens = 0
+        self.inference_count = 0
+        self.max_blocks_per_seq = -(-config.max_model_len // self.block_size)
+        self.builder = InputBuilder(self.block_size, config.max_num_seqs, config.max_model_len,
+                                    config.max_num_batched_tokens, pin_memory=self.device.type == "cuda")
+        ms = config.max_num_seqs
+        # device mirrors of the decode staging buffers (allocated once; inference_executor.py:149-180)
+        self._dev_i64 = torch.zeros((2, ms), dtype=torch.int64, device=self.device)
+        self._dev_slots = torch.zeros(ms, dtype=torch.int32, device=self.device)
+        self._dev_ctx = torch.zeros(ms, dtype=torch.int32, device=self.device)
+        self._dev_tables = torch.full((ms, self.max_blocks_per_seq), -1, dtype=torch.int32, device=self.device)
+        # sampling parameters: one pinned plane, one device plane  [temps | top_ps | min_ps] f32, top_ks i64
+        pin = self.device.type == "cuda"
+        self._samp_f32 = torch.zeros((3, ms), dtype=torch.float32, pin_memory=pin)
+        self._samp_i64 = torch.zeros((ms,), dtype=torch.int64, pin_memory=pin)
+        self._dev_samp_f32 = torch.zeros((3, ms), dtype=torch.float32, device=self.device)
+        self._dev_samp_i64 = torch.zeros((ms,), dtype=torch.int64, device=self.device)
+
+    # ------------------------------------------------------------------ set-up
+    def initialize(self, max_num_batched_tokens: int, max_num_seqs: int) -> None:
+        self._allocate_kv_cache()
+        self._initialize_sampler()
+        self._optimize_model()
+        self._warmup_model(max_num_batched_tokens, max_num_seqs)
+
+    def _calculate_num_kv_blocks(self) -> int:
+        """blocks = min(avail // block_bytes, max_num_seqs * ceil(max_model_len / bs)) with
+        avail = total*util - used - peak + current (inference_executor.py:245-318)."""
+        cfg = self.config
+        free, total = torch.cuda.mem_get_info(self.device)
+        stats = torch.cuda.memory_stats(self.device)
+        peak = stats.get("allocated_bytes.all.peak", 0)
+        current = stats.get("allocated_bytes.all.current", 0)
+        block_bytes = kv_block_bytes(self.num_layers, self.block_size, self.num_kv_heads, self.head_dim,
+                                     self.dtype.itemsize)
+        avail = int(total * cfg.device_memory_utilization - (total - free) - peak + current)
+        if avail <= 0:
+            raise RuntimeError(f"Insufficient memory for KV cache allocation. Device: {self.device.type}, "
+                               f"Available: {avail} bytes, Block size: {block_bytes} bytes")
+        cap = cfg.max_num_seqs * self.max_blocks_per_seq
+        n = min(avail // block_bytes, cap)
+        if n <= 0:
+            raise ValueError(f"Calculated KV cache blocks ({n}) must be > 0. Available memory: {avail} bytes, "
+                             f"Block size: {block_bytes} bytes")
+        return int(n)
+
+    def _allocate_kv_cache(self) -> None:
+        n = self.config.num_kvcache_blocks
+        if n <= 0:
+            n = self._calculate_num_kv_blocks()
+            self.config.num_kvcache_blocks = n  # the scheduler's BlockManager is sized from this
+        shape = (2, self.num_layers, n, self.block_size, self.num_kv_heads, self.head_dim)
+        try:
+            self.kv_cache = torch.empty(shape, device=self.device, dtype=self.dtype)
+        except torch.cuda.OutOfMemoryError as e:
+            raise RuntimeError(f"OOM during KV cache allocation. Try reducing device_memory_utilization "
+                               f"(current: {self.config.device_memory_utilization}) or max_num_seqs. Error: {e}") from e
+        self._assign_kv_cache_to_layers()
+        logger.info("Allocated KV cache: %.2f GB (%d blocks x %d tokens)",
+                    self.kv_cache.numel() * self.kv_cache.element_size() / 2**30, n, self.block_size)
+
+    def _assign_kv_cache_to_layers(self) -> None:
+        layer = 0
+        for module in self.model.modules():
+            if hasattr(module, "k_cache") and hasattr(module, "v_cache"):
+                module.k_cache, module.v_cache = self.kv_cache[0, layer], self.kv_cache[1, layer]
+                layer += 1
+        if layer == 0:
+            logger.warning("No attention layers found with k_cache/v_cache attributes.")
+
+    def _initialize_sampler(self) -> None:
+        self.sampler = Sampler(seed=self.config.seed)
+
+    def _optimize_model(self) -> None:
+        self.model.eval()
+        for p in self.model.parameters():
+            p.requires_grad = False
+
+    def _warmup_model(self, max_num_batched_tokens: int, max_num_seqs: int) -> None:
+        """2 x 16-token dummy prefill + one decode with EMPTY block tables
+        (inference_executor.py:373-410): exercises the no-slot / zero-column paths."""
+        mml = self.config.max_model_len
+        n = min(max_num_batched_tokens // max(mml // 2, 1), max_num_seqs, 2)
+        dummy = [Sequence([0] * min(16, mml), block_size=self.block_size) for _ in range(n)]
+        if not dummy:
+            return
+        self.execute_batch(dummy, prefill=True)
+        for s in dummy:
+            s.append_token(0)
+        self.execute_batch(dummy, prefill=False)
+        torch.cuda.synchronize(self.device)
+
+    # ------------------------------------------------------------------ one step
+    @torch.inference_mode()
+    def execute_batch(self, sequences: list[Sequence], prefill: bool = True):
+        """-> (logits [n, V], next_tokens list[int])."""
+        if not sequences:
+            return torch.empty(0, device=self.device), []
+        try:
+            if prefill:
+                inp = self.builder.prefill(sequences)
+                ids, pos = self._ship_prefill(inp, sequences)
+                logits = self.model.compute_logits(self.model(ids, pos))
+                tokens = self._sample_tokens(logits, sequences)
+            else:
+                inp = self.builder.decode(sequences)
+                bs = self._graph_bucket(len(sequences))
+                if bs is not None:
+                    logits, tokens = self._replay_graph(bs, inp, sequences)
+                else:
+                    ids, pos = self._ship_decode(inp)
+                    logits = self.model.compute_logits(self.model(ids, pos))
+                    tokens = self._sample_tokens(logits, sequences)
+            self._update_metrics(sequences, prefill)
+            self.inference_count += 1
+            return logits, tokens
+        finally:
+            reset_context()
+
+    def _to_dev(self, t: torch.Tensor | None):
+        return None if t is None else t.to(self.device, non_blocking=True)
+
+    def _ship_prefill(self, inp: BatchInputs, sequences):
+        set_context(True, inp.max_seqlen_q, inp.max_seqlen_k, self._to_dev(inp.cum_seqlens_q),
+                    self._to_dev(inp.cum_seqlens_k), self._to_dev(inp.slot_mapping), None,
+                    self._to_dev(inp.block_tables),
+                    prefix_cached=any(s.num_cached_tokens > 0 for s in sequences))
+        return self._to_dev(inp.input_ids), self._to_dev(inp.positions)
+
+    def _ship_decode(self, inp: BatchInputs):
+        b = inp.num_seqs
+        if b > self._dev_slots.shape[0]:  # oversize batch: one-off tensors
+            set_context(False, 0, 0, None, None, self._to_dev(inp.slot_mapping), self._to_dev(inp.context_lens),
+                        self._to_dev(inp.block_tables))
+            return self._to_dev(inp.input_ids), self._to_dev(inp.positions)
+        ids, pos = self._dev_i64[0, :b], self._dev_i64[1, :b]
+        ids.copy_(inp.input_ids, non_blocking=True)
+        pos.copy_(inp.positions, non_blocking=True)
+        slots, ctx = self._dev_slots[:b], self._dev_ctx[:b]
+        slots.copy_(inp.slot_mapping, non_blocking=True)
+        ctx.copy_(inp.context_lens, non_blocking=True)
+        w = inp.block_tables.shape[1]
+        if w and w <= self._dev_tables.shape[1]:
+            tables = self._dev_tables[:b, :w]  # row-strided view, like the reference
+            tables.copy_(inp.block_tables, non_blocking=True)
+        else:
+            tables = self._to_dev(inp.block_tables)
+        set_context(False, 0, 0, None, None, slots, ctx, tables)
+        return ids, pos
+
+    def _ship_sampling(self, sequences, b_pad: int | None = None):
+        b = len(sequences)
+        f, k = self._samp_f32.numpy(), self._samp_i64.numpy()
+        f[0, :b] = [s.temperature for s in sequences]
+        f[1, :b] = [s.top_p for s in sequences]
+        f[2, :b] = [s.min_p for s in sequences]
+        k[:b] = [s.top_k for s in sequences]
+        n = b if b_pad is None else b_pad
+        if n > b:  # padded graph rows: greedy, cheapest path
+            f[0, b:n], f[1, b:n], f[2, b:n], k[b:n] = 0.0, 1.0, 0.0, -1
+        self._dev_samp_f32[:, :n].copy_(self._samp_f32[:, :n], non_blocking=True)
+        self._dev_samp_i64[:n].copy_(self._samp_i64[:n], non_blocking=True)
+        d = self._dev_samp_f32
+        return d[0, :n], self._dev_samp_i64[:n], d[1, :n], d[2, :n]
+
+    def _sample_tokens(self, logits, sequences) -> list[int]:
+        if self.sampler is None:
+            return []
+        if len(sequences) > self._samp_i64.shape[0]:
+            dev = logits.device
+            t = torch.tensor([s.temperature for s in sequences], dtype=torch.float32, device=dev)
+            k = torch.tensor([s.top_k for s in sequences], dtype=torch.int64, device=dev)
+            p = torch.tensor([s.top_p for s in sequences], dtype=torch.float32, device=dev)
+            m = torch.tensor([s.min_p for s in sequences], dtype=torch.float32, device=dev)
+        else:
+            t, k, p, m = self._ship_sampling(sequences)
+        return self.sampler(logits, temperatures=t, top_ks=k, top_ps=p, min_ps=m).tolist()
+
+    def _update_metrics(self, sequences, prefill: bool) -> None:
+        if prefill:
+            self.total_prefill_tokens += sum(len(s) - s.num_cached_tokens for s in sequences)
+        else:
+            self.total_decode_tokens += len(sequences)
+        self.total_tokens_generated += len(sequences)
+
+    # ------------------------------------------------------------------ hipGraph decode
+    def _graph_bucket(self, batch_size: int) -> int | None:
+        if self.enforce_eager or not self.graphs:
+            return None
+        return next((bs for bs in self.graph_bs if bs >= batch_size and bs in self.graphs), None)
+
+    def capture_device_graphs(self, max_batch_size: int) -> None:
+        """Capture one hipGraph per decode batch-size bucket (largest first, shared pool)."""
+        if self.enforce_eager:
+            return
+        self.graph_bs = graph_batch_sizes(min(max_batch_size, self.config.max_num_seqs))
+        max_bs = self.graph_bs[-1]
+        hidden = self.config.hf_config.hidden_size
+        vocab = self.config.hf_config.vocab_size
+        dev = self.device
+        gv = self.graph_vars = {
+            "input_ids": torch.zeros(max_bs, dtype=torch.int64, device=dev),
+            "positions": torch.zeros(max_bs, dtype=torch.int64, device=dev),
+            "slot_mapping": torch.full((max_bs,), -1, dtype=torch.int32, device=dev),
+            "context_lens": torch.zeros(max_bs, dtype=torch.int32, device=dev),
+            "block_tables": torch.full((max_bs, self.max_blocks_per_seq), -1, dtype=torch.int32, device=dev),
+            "logits": torch.zeros((max_bs, vocab), dtype=self.dtype, device=dev),
+            "tokens": torch.zeros(max_bs, dtype=torch.int64, device=dev),
+            "rng_offset": torch.zeros(1, dtype=torch.int64, device=dev),
+        }
+        # the split-KV workspace must exist before capture (no allocation inside a graph)
+        hf = self.config.hf_config
+        heads = hf.num_attention_heads // get_tensor_parallel_world_size()
+        hip_ops.workspace(hip_ops.paged_decode_workspace_bytes(max_bs, heads, self.num_kv_heads, self.head_dim,
+                                                               self.block_size, self.max_blocks_per_seq), dev)
+        self.sampler.offset_dev = gv["rng_offset"]
+        try:
+            for bs in reversed(self.graph_bs):
+                self._capture_one(bs)
+            logger.info("Captured %d decode graphs (batch sizes %s..%d)", len(self.graphs),
+                        self.graph_bs[:4], self.graph_bs[-1])
+        except Exception as e:  # fall back to eager, loudly
+            logger.warning("Failed to capture device graphs: %s", e)
+            self.graphs.clear()
+            self.sampler.offset_dev = None
+            reset_context()
+
+    def _graph_forward(self, bs: int):
+        gv = self.graph_vars
+        set_context(False, 0, 0, None, None, gv["slot_mapping"][:bs], gv["context_lens"][:bs],
+                    gv["block_tables"][:bs])
+        hidden = self.model(gv["input_ids"][:bs], gv["positions"][:bs])
+        logits = self.model.compute_logits(hidden)
+        gv["logits"][:bs].copy_(logits)
+        d = self._dev_samp_f32
+        toks = hip_ops.sample(gv["logits"][:bs], d[0, :bs], self._dev_samp_i64[:bs], d[1, :bs], d[2, :bs],
+                              seed=self.sampler.seed, offset=0, offset_dev=gv["rng_offset"])
+        gv["tokens"][:bs].copy_(toks)
+
+    @torch.inference_mode()
+    def _capture_one(self, bs: int) -> None:
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):  # warm-up on a side stream (RCCL / hipBLASLt lazy init)
+            self._graph_forward(bs)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, pool=self.graph_pool):
+            self._graph_forward(bs)
+        if self.graph_pool is None:
+            self.graph_pool = graph.pool()
+        self.graphs[bs] = graph
+        torch.cuda.synchronize(self.device)
+        reset_context()
+
+    def _replay_graph(self, bs: int, inp: BatchInputs, sequences):
+        gv = self.graph_vars
+        b = inp.num_seqs
+        gv["input_ids"][:b].copy_(inp.input_ids, non_blocking=True)
+        gv["positions"][:b].copy_(inp.positions, non_blocking=True)
+        if bs > b:  # padded rows: no store (-1 slot), empty context
+            gv["slot_mapping"][b:bs].fill_(-1)
+            gv["context_lens"][b:bs].zero_()
+        gv["slot_mapping"][:b].copy_(inp.slot_mapping, non_blocking=True)
+        gv["context_lens"][:b].copy_(inp.context_lens, non_blocking=True)
+        w = inp.block_tables.shape[1]
+        if w:
+            gv["block_tables"][:b, :w].copy_(inp.block_tables, non_blocking=True)
+        self._ship_sampling(sequences, b_pad=bs)
+        self.sampler.calls += 1
+        gv["rng_offset"].fill_(self.sampler.calls)
+        self.graphs[bs].replay()
+        return gv["logits"][:b], gv["tokens"][:b].tolist()
+
+    def cleanup(self) -> None:
+        self.graphs.clear()
+        self.graph_vars.clear()
+        self.graph_pool = None
+        self.kv_cache = None
+        self.model = None
+        self.sampler = None
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()

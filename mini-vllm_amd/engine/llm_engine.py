@@ -1,0 +1,173 @@
+"""Request loop (mirror of minivllm/engine/llm_engine.py:40-367): tokenize -> schedule -> run ->
+postprocess until every request has finished.
+
+Tensor parallelism is SPMD.  With ``tensor_parallel_size > 1`` either
+  * the process was launched by ``torch.distributed.run`` (RANK/WORLD_SIZE set): every rank builds
+    its own engine and calls ``generate`` with the same arguments, or
+  * rank 0 spawns the other ranks (one process per GPU, like the reference); each ``generate`` call
+    is broadcast once over the host control group and then runs identically everywhere.
+Scheduling, block allocation and sampling (Philox keyed by seed/step/row) are deterministic, so
+all ranks stay in lock-step without any per-step control traffic."""
+from __future__ import annotations
+
+import atexit
+import logging
+import os
+import socket
+import warnings
+from time import perf_counter
+
+import torch.multiprocessing as mp
+
+from ..config import Config
+from ..sampling_params import SamplingParams
+from .model_runner import ModelRunner
+from .scheduler import Scheduler
+from .sequence import Sequence
+
+logger = logging.getLogger(__name__)
+__all__ = ["LLMEngine"]
+
+
+def _worker_main(config: Config, rank: int) -> None:
+    os.environ["LOCAL_RANK"] = str(rank)
+    engine = LLMEngine(config, _rank=rank)
+    dm = engine.model_runner.distributed_manager
+    while True:
+        cmd = dm.broadcast_data(None, src=0)
+        if cmd[0] == "exit":
+            break
+        if cmd[0] == "generate":
+            engine._generate_local(cmd[1], cmd[2], use_tqdm=False)
+    engine.model_runner.exit()
+
+
+class LLMEngine:
+    def __init__(self, config: Config, model_runner=None, _rank: int | None = None) -> None:
+        if not isinstance(config, Config):
+            raise TypeError(f"config must be a Config instance, got {type(config).__name__}")
+        self.config = config
+        self.ps: list = []
+        self.events: list = []
+        tp = config.tensor_parallel_size
+        launched = _rank is not None or (tp > 1 and int(os.environ.get("WORLD_SIZE", "1")) == tp
+                                         and "RANK" in os.environ and "TORCHELASTIC_RUN_ID" in os.environ)
+        self.rank = _rank if _rank is not None else int(os.environ.get("RANK", "0")) if launched else 0
+        self._is_driver = tp > 1 and not launched
+        if model_runner is not None:            # injected runner (tests drive the host logic with it)
+            self.model_runner = model_runner
+        else:
+            if self._is_driver:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+                    sock.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+                ctx = mp.get_context("spawn")
+                for i in range(1, tp):
+                    p = ctx.Process(target=_worker_main, args=(config, i))
+                    p.start()
+                    self.ps.append(p)
+            self.model_runner = ModelRunner(config, self.rank, self.events)
+        mm = getattr(self.model_runner, "model_manager", None)
+        self.tokenizer = getattr(mm, "tokenizer", None)
+        if self.tokenizer is not None and self.tokenizer.eos_token_id is not None:
+            config.eos = self.tokenizer.eos_token_id
+        elif config.eos == -1:
+            eos = getattr(config.hf_config, "eos_token_id", None)
+            config.eos = eos[0] if isinstance(eos, (list, tuple)) else (eos if eos is not None else -1)
+        self.scheduler = Scheduler(config)
+        atexit.register(self.exit)
+
+    def exit(self) -> None:
+        runner = self.__dict__.pop("model_runner", None)
+        if runner is None:
+            return
+        try:
+            if self._is_driver:
+                runner.distributed_manager.broadcast_data(("exit",), src=0)
+            runner.call("exit")
+        except Exception as e:
+            warnings.warn(f"Errors during engine cleanup: {e}", RuntimeWarning, stacklevel=2)
+        for i, p in enumerate(self.ps):
+            p.join(timeout=10)
+            if p.is_alive():
+                warnings.warn(f"Worker process {i} did not terminate gracefully, forcing termination",
+                              RuntimeWarning, stacklevel=2)
+                p.terminate()
+                p.join(timeout=2)
+                if p.is_alive():
+                    p.kill()
+        self.ps.clear()
+
+    # ------------------------------------------------------------------ requests
+    def add_request(self, prompt: str | list[int], sampling_params: SamplingParams | None = None) -> int:
+        if sampling_params is None:
+            sampling_params = SamplingParams()
+        if isinstance(prompt, str):
+            if self.tokenizer is None:
+                raise RuntimeError("no tokenizer loaded: pass prompts as lists of token ids")
+            prompt = self.tokenizer.encode(prompt)
+        seq = Sequence(prompt, sampling_params, block_size=self.config.kvcache_block_size)
+        self.scheduler.add(seq)
+        return seq.seq_id
+
+    def step(self):
+        """-> ([(seq_id, completion_token_ids) for finished], +prefill tokens | -decode seqs)."""
+        sequences, is_prefill = self.scheduler.schedule()
+        token_ids = self.model_runner.call("run", sequences, is_prefill)
+        if token_ids is None:
+            raise RuntimeError("ModelRunner returned no tokens on rank 0")
+        self.scheduler.postprocess(sequences, token_ids)
+        outputs = [(s.seq_id, s.completion_token_ids) for s in sequences if s.is_finished]
+        num_tokens = sum(len(s) for s in sequences) if is_prefill else -len(sequences)
+        return outputs, num_tokens
+
+    def is_finished(self) -> bool:
+        return self.scheduler.is_finished()
+
+    def generate(self, prompts, sampling_params=None, use_tqdm: bool = True):
+        if self._is_driver:
+            if self.tokenizer is not None:   # ship token ids: workers need no tokenizer round trip
+                prompts = [self.tokenizer.encode(p) if isinstance(p, str) else p for p in prompts]
+            self.model_runner.distributed_manager.broadcast_data(("generate", prompts, sampling_params), src=0)
+        return self._generate_local(prompts, sampling_params, use_tqdm)
+
+    def _generate_local(self, prompts, sampling_params, use_tqdm: bool):
+        if sampling_params is None:
+            sp_list = [SamplingParams() for _ in prompts]
+        elif not isinstance(sampling_params, list):
+            sp_list = [sampling_params] * len(prompts)
+        else:
+            if len(sampling_params) != len(prompts):
+                raise ValueError("Length of sampling_params list must match prompts")
+            sp_list = sampling_params
+        pbar = None
+        if use_tqdm and self.rank == 0:
+            from tqdm.auto import tqdm
+
+            pbar = tqdm(total=len(prompts), desc="Generating", dynamic_ncols=True)
+        ids = [self.add_request(p, sp) for p, sp in zip(prompts, sp_list)]
+        outputs: dict[int, list[int]] = {}
+        prefill_tps = decode_tps = 0.0
+        while not self.is_finished():
+            t0 = perf_counter()
+            finished, num_tokens = self.step()
+            dt = perf_counter() - t0
+            if num_tokens > 0:
+                prefill_tps = num_tokens / dt
+            else:
+                decode_tps = -num_tokens / dt
+            if pbar is not None:
+                pbar.set_postfix({"Prefill": f"{int(prefill_tps)} token/s", "Decode": f"{int(decode_tps)} token/s"})
+            for seq_id, toks in finished:
+                outputs[seq_id] = toks
+                if pbar is not None:
+                    pbar.update(1)
+        if pbar is not None:
+            pbar.close()
+        ordered = [outputs[i] for i in sorted(ids) if i in outputs]
+        if self.tokenizer is not None:
+            texts = self.tokenizer.batch_decode(ordered, skip_special_tokens=True, clean_up_tokenization_spaces=True)
+        else:
+            texts = [""] * len(ordered)
+        return [{"text": t, "token_ids": toks} for t, toks in zip(texts, ordered)]

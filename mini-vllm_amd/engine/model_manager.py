@@ -1,0 +1,123 @@
+"""Model + tokenizer lifecycle (mirror of minivllm/models/manager.py:31-242) for one GPU of the
+tensor-parallel group.  Parameters are created directly on the device in the serving dtype
+(a 72B shard never exists in fp32 on the host), then filled from the checkpoint or — with
+``Config.load_format == "dummy"`` — random-initialised at the true architecture dimensions."""
+from __future__ import annotations
+
+import logging
+import os
+
+import torch
+
+from ..config import Config
+from ..glue import create_model
+from ..utils.loader import has_weight_files, load_model
+
+logger = logging.getLogger(__name__)
+__all__ = ["ModelManager", "resolve_dtype"]
+
+_DTYPES = {"float16": torch.float16, "bfloat16": torch.bfloat16, "float32": torch.float32}
+
+
+def resolve_dtype(config: Config) -> torch.dtype:
+    if config.dtype != "auto":
+        return _DTYPES[config.dtype]
+    # the reference leaves "auto" at fp32 whatever the checkpoint says; here it
+    # means what it says: the checkpoint's own dtype
+    hf = getattr(config.hf_config, "torch_dtype", None) or getattr(config.hf_config, "dtype", None)
+    if isinstance(hf, str):
+        hf = _DTYPES.get(hf.replace("torch.", ""))
+    return hf if hf in _DTYPES.values() else torch.float32
+
+
+class ModelManager:
+    def __init__(self, config: Config) -> None:
+        self.config = config
+        self.device: torch.device | None = None
+        self.model = None
+        self.tokenizer = None
+        self.model_type: str | None = None
+
+    def initialize(self) -> None:
+        self._setup_device()
+        if not self.config.model:
+            raise ValueError("Model path cannot be empty")
+        self._load_tokenizer()
+        self._load_model()
+        self._validate()
+
+    def _setup_device(self) -> None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("minivllm_amd needs a ROCm GPU (MI355X): the inference hot path runs on "
+                               "hand-written HIP kernels and has no CPU fallback")
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(self.device)
+
+    def _load_tokenizer(self) -> None:
+        from transformers import AutoTokenizer
+
+        try:
+            tok = AutoTokenizer.from_pretrained(self.config.model, trust_remote_code=True, use_fast=True,
+                                                local_files_only=True)
+            if tok.pad_token is None:
+                tok.pad_token = tok.eos_token
+            self.tokenizer = tok
+        except Exception as e:
+            if self.config.load_format != "dummy":
+                raise RuntimeError(f"Failed to load tokenizer: {e}") from e
+            logger.warning("no tokenizer in %s: prompts must be token-id lists", self.config.model)
+            self.tokenizer = None
+
+    def _load_model(self) -> None:
+        cfg = self.config
+        dtype = resolve_dtype(cfg)
+        prev = torch.get_default_dtype()
+        try:
+            torch.set_default_dtype(dtype)
+            with torch.device(self.device):
+                model = create_model(cfg.hf_config)
+        finally:
+            torch.set_default_dtype(prev)
+        self.model_type = type(model).__name__.replace("ForCausalLM", "").lower()
+        if cfg.load_format == "dummy" or (cfg.load_format == "auto" and not has_weight_files(cfg.model)
+                                          and os.environ.get("MINIVLLM_DUMMY_WEIGHTS") == "1"):
+            self._dummy_init(model, cfg.seed if cfg.seed is not None else 0)
+        else:
+            load_model(model, cfg.model)
+        # params already have `dtype`; this also casts the RoPE tables like the reference's
+        # model.to(device, dtype) does (its bf16 runs rotate with bf16-rounded cos/sin)
+        self.model = model.to(device=self.device, dtype=dtype)
+
+    @staticmethod
+    def _dummy_init(model, seed: int) -> None:
+        gen = torch.Generator(device=next(model.parameters()).device).manual_seed(seed)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if "norm" in name and name.endswith("weight"):
+                    p.fill_(1.0)
+                elif name.endswith("bias"):
+                    p.zero_()
+                else:
+                    p.normal_(0.0, 0.02, generator=gen)
+
+    def _validate(self) -> None:
+        c = self.model.config
+        for field in ("vocab_size", "hidden_size", "num_attention_heads"):
+            if getattr(c, field, 0) <= 0:
+                raise ValueError(f"Invalid {field}: {getattr(c, field, 0)}")
+
+    def get_model_info(self) -> dict:
+        if self.model is None:
+            return {}
+        c = self.model.config
+        return {"model_type": self.model_type, "device": str(self.device), "vocab_size": c.vocab_size,
+                "hidden_size": c.hidden_size, "num_layers": c.num_hidden_layers,
+                "num_heads": c.num_attention_heads, "dtype": str(self.config.dtype),
+                "tensor_parallel_size": self.config.tensor_parallel_size}
+
+    def cleanup(self) -> None:
+        self.model = None
+        self.tokenizer = None
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()

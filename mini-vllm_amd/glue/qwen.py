@@ -1,0 +1,220 @@
+"""Qwen2 / Qwen3 decoder glue (mirror of minivllm/models/qwen_base.py, qwen2.py, qwen3.py).
+
+Op order per layer fixes the fusion boundaries:
+    qkv GEMM -> [q/k head RMSNorm] -> RoPE -> KV store   == ONE HIP launch (mv_rope_qk_store)
+    -> attention (varlen prefill | paged decode)          == ONE HIP launch
+    -> o_proj (+all-reduce) -> add+RMSNorm (fused HIP) -> gate_up GEMM -> SiluAndMul (HIP)
+    -> down GEMM (+all-reduce) -> add+RMSNorm (fused HIP)
+GEMMs go to hipBLASLt through F.linear.  Qwen2 = qkv bias, no qk-norm, theta 1e6;
+Qwen3 = no bias, per-head q/k RMSNorm, theta 1e4 default (qwen2.py:23-25, qwen3.py:23-25).
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+from torch import nn
+
+from .. import hip_ops
+from ..layers import (Attention, MergedColumnParallelLinear, ParallelLMHead, QKVParallelLinear, RMSNorm,
+                      RowParallelLinear, SiluAndMul, VocabParallelEmbedding, get_rope)
+from ..parallel_state import get_tensor_parallel_world_size
+from ..utils.context import get_context
+
+__all__ = ["QwenAttention", "QwenMLP", "QwenDecoderLayer", "QwenModel", "QwenForCausalLM",
+           "Qwen2ForCausalLM", "Qwen3ForCausalLM"]
+
+
+def _rope_theta(config, default: float) -> float:
+    """transformers >= 5 moved rope_theta into ``rope_parameters`` (qwen_base.py:31-41)."""
+    if hasattr(config, "rope_theta"):
+        return config.rope_theta
+    for attr in ("rope_parameters", "rope_scaling"):
+        d = getattr(config, attr, None) or {}
+        if isinstance(d, dict) and "rope_theta" in d:
+            return d["rope_theta"]
+    return default
+
+
+def _rope_scaling(config) -> dict[str, Any] | None:
+    raw = getattr(config, "rope_scaling", None)
+    if not isinstance(raw, dict):
+        return None
+    keep = {"factor", "type", "low_freq_factor", "high_freq_factor", "original_max_position_embeddings",
+            "short_factor", "long_factor"}
+    return {k: v for k, v in raw.items() if k in keep} or None
+
+
+class QwenAttention(nn.Module):
+    default_qkv_bias: bool = True
+    default_rope_theta: float = 1000000
+
+    def __init__(self, hidden_size: int, num_heads: int, num_kv_heads: int, max_position: int = 4096 * 32,
+                 head_dim: int | None = None, rms_norm_eps: float = 1e-06, qkv_bias: bool | None = None,
+                 rope_theta: float | None = None, rope_scaling: dict[str, Any] | None = None,
+                 use_buffered_page_attention: bool = False) -> None:
+        super().__init__()
+        qkv_bias = self.default_qkv_bias if qkv_bias is None else qkv_bias
+        rope_theta = self.default_rope_theta if rope_theta is None else rope_theta
+        tp = get_tensor_parallel_world_size()
+        self.total_num_heads, self.total_num_kv_heads = num_heads, num_kv_heads
+        if num_heads % tp != 0:
+            raise ValueError(f"total_num_heads ({num_heads}) must be divisible by tp_size ({tp})")
+        if num_kv_heads % tp != 0:
+            raise ValueError(f"total_num_kv_heads ({num_kv_heads}) must be divisible by tp_size ({tp})")
+        self.num_heads, self.num_kv_heads = num_heads // tp, num_kv_heads // tp
+        self.head_dim = int(head_dim or (hidden_size // num_heads))
+        self.q_size, self.kv_size = self.num_heads * self.head_dim, self.num_kv_heads * self.head_dim
+        self.scaling = self.head_dim ** -0.5
+        self.qkv_bias = qkv_bias
+        self.rms_norm_eps = float(rms_norm_eps)
+        self.qkv_proj = QKVParallelLinear(hidden_size, self.head_dim, num_heads, num_kv_heads, bias=qkv_bias)
+        self.o_proj = RowParallelLinear(num_heads * self.head_dim, hidden_size, bias=False)
+        self.rotary_emb = get_rope(self.head_dim, rotary_dim=self.head_dim, max_position=max_position,
+                                   base=rope_theta, rope_scaling=rope_scaling)
+        self.attn = Attention(self.num_heads, self.head_dim, self.scaling, self.num_kv_heads)
+        # q/k head norms exist iff there is no qkv bias (Qwen3), qwen_base.py:139-144
+        self.q_norm = None if qkv_bias else RMSNorm(self.head_dim, eps=rms_norm_eps)
+        self.k_norm = None if qkv_bias else RMSNorm(self.head_dim, eps=rms_norm_eps)
+
+    def forward(self, positions, hidden_states):
+        lead = hidden_states.shape[:-1]
+        if hidden_states.dim() == 3:  # [B,S,h]: same math on the flattened tokens
+            hidden_states = hidden_states.reshape(-1, hidden_states.shape[-1])
+            positions = positions.reshape(-1)
+        t = hidden_states.shape[0]
+        qkv = self.qkv_proj(hidden_states)
+        q = qkv[:, :self.q_size].view(t, self.num_heads, self.head_dim)
+        k = qkv[:, self.q_size:self.q_size + self.kv_size].view(t, self.num_kv_heads, self.head_dim)
+        v = qkv[:, self.q_size + self.kv_size:].view(t, self.num_kv_heads, self.head_dim)
+        ctx = get_context()
+        attn = self.attn
+        has_cache = attn.k_cache.numel() > 0
+        cos, sin = self.rotary_emb._tables(qkv.device)
+        # prefill over contiguous K needs the rotated keys as a tensor; decode and prefix-cached
+        # prefill read them back from the paged cache
+        want_k = ctx.is_prefill and not (ctx.prefix_cached and has_cache)
+        q_rot, k_rot = hip_ops.rope_qk_store(
+            q, k, v, positions, cos, sin,
+            None if self.q_norm is None else self.q_norm.weight,
+            None if self.k_norm is None else self.k_norm.weight, self.rms_norm_eps,
+            attn.k_cache if has_cache else None, attn.v_cache if has_cache else None,
+            ctx.slot_mapping if has_cache else None, want_k_out=want_k)
+        o = attn(q_rot, k_rot, v, kv_stored=True)
+        out = self.o_proj(o.view(t, self.q_size))
+        return out.view(*lead, out.shape[-1])
+
+    def extra_repr(self) -> str:
+        return (f"num_heads={self.num_heads}, num_kv_heads={self.num_kv_heads}, head_dim={self.head_dim}, "
+                f"qkv_bias={self.qkv_bias}")
+
+
+class QwenMLP(nn.Module):
+    def __init__(self, hidden_size: int, intermediate_size: int, hidden_act: str) -> None:
+        super().__init__()
+        if hidden_act != "silu":
+            raise ValueError(f"Unsupported activation function: '{hidden_act}'. Supported activations: ['silu']")
+        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size] * 2, bias=False)
+        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, bias=False)
+        self.act_fn = SiluAndMul()
+        self.hidden_act, self.intermediate_size, self.hidden_size = hidden_act, intermediate_size, hidden_size
+
+    def forward(self, x):
+        return self.down_proj(self.act_fn(self.gate_up_proj(x)))
+
+
+class QwenDecoderLayer(nn.Module):
+    attention_cls = QwenAttention
+
+    def __init__(self, config) -> None:
+        super().__init__()
+        acls = self.attention_cls
+        self.self_attn = acls(
+            hidden_size=config.hidden_size, num_heads=config.num_attention_heads,
+            num_kv_heads=config.num_key_value_heads, max_position=config.max_position_embeddings,
+            rms_norm_eps=config.rms_norm_eps, qkv_bias=getattr(config, "attention_bias", acls.default_qkv_bias),
+            head_dim=getattr(config, "head_dim", None), rope_theta=_rope_theta(config, acls.default_rope_theta),
+            rope_scaling=_rope_scaling(config))
+        self.mlp = QwenMLP(config.hidden_size, config.intermediate_size, config.hidden_act)
+        self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, positions, hidden_states, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states, _ = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        return self.mlp(hidden_states), residual
+
+
+class QwenModel(nn.Module):
+    decoder_layer_cls = QwenDecoderLayer
+
+    def __init__(self, config) -> None:
+        super().__init__()
+        self.config = config
+        self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList(self.decoder_layer_cls(config) for _ in range(config.num_hidden_layers))
+        self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, input_ids, positions):
+        hidden_states, residual = self.embed_tokens(input_ids), None
+        for layer in self.layers:
+            hidden_states, residual = layer(positions, hidden_states, residual)
+        hidden_states, _ = self.norm(hidden_states, residual)
+        return hidden_states
+
+
+class QwenForCausalLM(nn.Module):
+    model_cls = QwenModel
+    # checkpoint name fragment -> (fused parameter, shard id)   (qwen_base.py:330-336)
+    packed_modules_mapping = {"q_proj": ("qkv_proj", "q"), "k_proj": ("qkv_proj", "k"), "v_proj": ("qkv_proj", "v"),
+                              "gate_proj": ("gate_up_proj", 0), "up_proj": ("gate_up_proj", 1)}
+
+    def __init__(self, config) -> None:
+        super().__init__()
+        self.config = config
+        self.model = self.model_cls(config)
+        self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size)
+        if getattr(config, "tie_word_embeddings", False):
+            self.lm_head.weight = self.model.embed_tokens.weight
+
+    def forward(self, input_ids, positions):
+        return self.model(input_ids, positions)
+
+    def compute_logits(self, hidden_states):
+        return self.lm_head(hidden_states)
+
+    def set_kv_cache(self, kv_cache) -> None:
+        for layer, (k, v) in zip(self.model.layers, kv_cache):
+            layer.self_attn.attn.k_cache, layer.self_attn.attn.v_cache = k, v
+
+    def load_weights(self, weights: dict[str, Any]) -> None:
+        from ..utils.loader import load_weight
+
+        for name, tensor in weights.items():
+            if "rotary_emb.inv_freq" not in name:
+                load_weight(self, name, tensor, self.packed_modules_mapping)
+
+
+class Qwen2Attention(QwenAttention):
+    default_qkv_bias = True
+    default_rope_theta = 1000000
+
+
+class Qwen3Attention(QwenAttention):
+    default_qkv_bias = False
+    default_rope_theta = 10000
+
+
+def _family(attention):
+    layer = type(f"{attention.__name__[:5]}DecoderLayer", (QwenDecoderLayer,), {"attention_cls": attention})
+    model = type(f"{attention.__name__[:5]}Model", (QwenModel,), {"decoder_layer_cls": layer})
+    return type(f"{attention.__name__[:5]}ForCausalLM", (QwenForCausalLM,), {"model_cls": model})
+
+
+Qwen2ForCausalLM = _family(Qwen2Attention)
+Qwen3ForCausalLM = _family(Qwen3Attention)

@@ -1,0 +1,57 @@
+"""Vocab-parallel embedding and LM head (mirror of minivllm/models/layers/embed_head.py:43-231)."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..parallel_state import (get_tensor_parallel_rank, get_tensor_parallel_world_size,
+                              tp_all_gather_last_dim, tp_all_reduce)
+from ..utils.context import get_context
+
+__all__ = ["VocabParallelEmbedding", "ParallelLMHead", "get_tensor_parallel_rank",
+           "get_tensor_parallel_world_size"]
+
+
+class VocabParallelEmbedding(nn.Module):
+    def __init__(self, num_embeddings: int, embedding_dim: int):
+        super().__init__()
+        self.tp_rank, self.tp_size = get_tensor_parallel_rank(), get_tensor_parallel_world_size()
+        if num_embeddings % self.tp_size != 0:
+            raise ValueError(f"num_embeddings ({num_embeddings}) must be divisible by "
+                             f"tensor-parallel size ({self.tp_size})")
+        self.num_embeddings = num_embeddings
+        self.num_embeddings_per_partition = num_embeddings // self.tp_size
+        self.vocab_start_idx = self.num_embeddings_per_partition * self.tp_rank
+        self.vocab_end_idx = self.vocab_start_idx + self.num_embeddings_per_partition
+        self.weight = nn.Parameter(torch.empty(self.num_embeddings_per_partition, embedding_dim))
+        self.weight.weight_loader = self.weight_loader
+
+    def weight_loader(self, param, loaded_weight, *args, **kwargs):
+        shard = param.data.size(0)
+        param.data.copy_(loaded_weight.narrow(0, self.tp_rank * shard, shard))
+
+    def extra_repr(self) -> str:
+        return (f"num_embeddings={self.num_embeddings}, embedding_dim={self.weight.shape[1]}, "
+                f"tp_size={self.tp_size}, tp_rank={self.tp_rank}")
+
+    def forward(self, x):
+        if self.tp_size == 1:
+            return F.embedding(x, self.weight)
+        mine = (x >= self.vocab_start_idx) & (x < self.vocab_end_idx)
+        y = F.embedding(mine * (x - self.vocab_start_idx), self.weight)
+        return tp_all_reduce(mine.unsqueeze(-1) * y)
+
+
+class ParallelLMHead(VocabParallelEmbedding):
+    def __init__(self, num_embeddings: int, embedding_dim: int, bias: bool = False):
+        if bias:
+            raise ValueError("bias for ParallelLMHead is not supported")
+        super().__init__(num_embeddings, embedding_dim)
+
+    def forward(self, x):
+        ctx = get_context()
+        if ctx.is_prefill:  # only each sequence's last token is sampled
+            x = x[(ctx.cum_seqlens_q[1:] - 1).long()].contiguous()
+        logits = F.linear(x, self.weight)
+        return tp_all_gather_last_dim(logits) if self.tp_size > 1 else logits

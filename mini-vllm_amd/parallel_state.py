@@ -1,0 +1,57 @@
+"""Tensor-parallel process state: one process per GPU, torch.distributed ("nccl" = RCCL over
+xGMI).  Set ONCE, before the model is built — the reference derives tp_size from
+``dist.is_initialized()`` while constructing layers but only initialises the process group
+afterwards, so its TP>1 silently builds replicated models."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+_state = {"rank": 0, "size": 1, "group": None}
+
+
+def init_tensor_parallel(rank: int, size: int, group=None) -> None:
+    if size < 1 or not 0 <= rank < size:
+        raise ValueError(f"invalid tensor-parallel rank/size {rank}/{size}")
+    _state.update(rank=rank, size=size, group=group)
+
+
+def reset_tensor_parallel() -> None:
+    _state.update(rank=0, size=1, group=None)
+
+
+def get_tensor_parallel_rank() -> int:
+    return _state["rank"]
+
+
+def get_tensor_parallel_world_size() -> int:
+    return _state["size"]
+
+
+def get_tensor_parallel_group():
+    return _state["group"]
+
+
+def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
+    """In-place SUM over the TP group (C1/C2: after o_proj, down_proj and the embedding)."""
+    if _state["size"] > 1:
+        dist.all_reduce(x, group=_state["group"])
+    return x
+
+
+def tp_all_gather_last_dim(x: torch.Tensor) -> torch.Tensor:
+    """Concatenate vocab shards along the last dim on EVERY rank (C3).  The reference gathers to
+    rank 0 only (embed_head.py:219-229); here all ranks run the same scheduler and sampler, so
+    each needs the full row and no per-step control broadcast exists."""
+    n = _state["size"]
+    if n == 1:
+        return x
+    out = torch.empty((n,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous(), group=_state["group"])
+    return out.movedim(0, -2).reshape(*x.shape[:-1], n * x.shape[-1])
+
+
+def divide(numerator: int, denominator: int) -> int:
+    if numerator % denominator != 0:
+        raise ValueError(f"{numerator} is not divisible by {denominator}")
+    return numerator // denominator

@@ -21,6 +21,9 @@ class Context:
     slot_mapping: torch.Tensor | None = None    # int32 [tokens]; -1 = skip
     context_lens: torch.Tensor | None = None    # int32 [B], decode only
     block_tables: torch.Tensor | None = None    # int32 [B, blocks], -1 padded
+    # build-only hint (not in the reference): some sequence of this prefill batch has a cached
+    # prefix, so keys must be read from the paged cache instead of the contiguous k/v
+    prefix_cached: bool = False
 
 
 _CURRENT: ContextVar[Context | None] = ContextVar("minivllm_amd_context", default=None)
@@ -33,9 +36,9 @@ def get_context() -> Context:
 
 def set_context(is_prefill: bool, max_seqlen_q: int = 0, max_seqlen_k: int = 0,
                 cum_seqlens_q=None, cum_seqlens_k=None, slot_mapping=None, context_lens=None,
-                block_tables=None) -> None:
+                block_tables=None, prefix_cached: bool = False) -> None:
     _CURRENT.set(Context(is_prefill, max_seqlen_q, max_seqlen_k, cum_seqlens_q, cum_seqlens_k,
-                         slot_mapping, context_lens, block_tables))
+                         slot_mapping, context_lens, block_tables, prefix_cached))
 
 
 def reset_context() -> None:
