@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decode tokens/s of the paged-attention inference path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[2]): Qwen3-1.7B, bf16, kvcache_block_size=64,
+hipGraph decode, max_num_seqs=256 — B=256 sequences at context 1024, synthetic token ids,
+random-initialised weights at the true architecture dimensions (no checkpoints offline; throughput is
+value-independent).  One "step" = one engine decode step over the whole batch: scheduler ->
+input prep -> H2D -> graph replay (28 layers + LM head + sampler) -> D2H of the B tokens ->
+postprocess.  value = B * K / wall time (max over ranks).  With N>1 the same model runs
+tensor-parallel over N GPUs (RCCL all-reduce over xGMI): total work fixed => "strong" scaling.
+
+Also reported on the same line:
+  roofline     — the dominant kernel (paged-KV decode attention): algorithmic bytes per launch /
+                 average launch time, timed with HIP events on the launching stream on the LIVE
+                 block tables / context lengths / KV cache of this run
+  cpu_baseline — the CPU restatement of the reference's eager path (oracle/, "port") timed on this
+                 host's cores on a bounded sample of the same model
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MODELS = {
+    # public HF config.json values
+    "qwen3-1.7b": dict(model_type="qwen3", architectures=["Qwen3ForCausalLM"], hidden_size=2048,
+                       num_hidden_layers=28, num_attention_heads=16, num_key_value_heads=8, head_dim=128,
+                       intermediate_size=6144, vocab_size=151936, max_position_embeddings=40960,
+                       rms_norm_eps=1e-6, rope_theta=1000000.0, tie_word_embeddings=True, hidden_act="silu",
+                       attention_bias=False, torch_dtype="bfloat16", eos_token_id=151645),
+    "qwen3-0.6b": dict(model_type="qwen3", architectures=["Qwen3ForCausalLM"], hidden_size=1024,
+                       num_hidden_layers=28, num_attention_heads=16, num_key_value_heads=8, head_dim=128,
+                       intermediate_size=3072, vocab_size=151936, max_position_embeddings=40960,
+                       rms_norm_eps=1e-6, rope_theta=1000000.0, tie_word_embeddings=True, hidden_act="silu",
+                       attention_bias=False, torch_dtype="bfloat16", eos_token_id=151645),
+    "qwen2-7b": dict(model_type="qwen2", architectures=["Qwen2ForCausalLM"], hidden_size=3584,
+                     num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4,
+                     intermediate_size=18944, vocab_size=152064, max_position_embeddings=32768,
+                     rms_norm_eps=1e-6, rope_theta=1000000.0, tie_word_embeddings=False, hidden_act="silu",
+                     torch_dtype="bfloat16", eos_token_id=151645),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="qwen3-1.7b", choices=list(MODELS))
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--ctx", type=int, default=1024)
+    ap.add_argument("--eager", action="store_true", help="enforce_eager (no hipGraph)")
+    ap.add_argument("--synthetic-kv", action="store_true",
+                    help="fill the KV cache with random values instead of running the prompt prefill")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def build_engine(args, workdir):
+    from minivllm_amd import LLM, Config
+
+    with open(os.path.join(workdir, "config.json"), "w") as f:
+        json.dump(MODELS[args.model], f)
+    max_len = max(4096, args.ctx + args.steps + args.warmup + 64)
+    cfg = Config(workdir, dtype="bfloat16", kvcache_block_size=64, max_num_seqs=args.batch,
+                 max_model_len=max_len, max_num_batched_tokens=max(16384, max_len),
+                 tensor_parallel_size=args.gpus, enforce_eager=args.eager, load_format="dummy", seed=0,
+                 num_kvcache_blocks=args.batch * (-(-(args.ctx + args.steps + args.warmup + 8) // 64) + 1))
+    return LLM(cfg)
+
+
+def fill_prompts(engine, args):
+    """B requests of ctx synthetic tokens each -> running sequences with allocated blocks."""
+    from minivllm_amd import SamplingParams
+
+    g = torch.Generator().manual_seed(0)
+    vocab = MODELS[args.model]["vocab_size"]
+    sp = SamplingParams(temperature=0.0, max_tokens=args.steps + args.warmup + 16, ignore_eos=True)
+    for _ in range(args.batch):
+        engine.add_request(torch.randint(0, vocab, (args.ctx,), generator=g).tolist(), sp)
+    prefill_tokens, t0 = 0, time.perf_counter()
+    if args.synthetic_kv:
+        ex = engine.model_runner.inference_executor
+        ex.kv_cache.normal_(0.0, 1.0)
+        while engine.scheduler.waiting:
+            batch, is_prefill = engine.scheduler.schedule()
+            assert is_prefill
+            engine.scheduler.postprocess(batch, [1] * len(batch))
+        return None
+    while engine.scheduler.waiting:
+        _, n = engine.step()
+        prefill_tokens += max(n, 0)
+    torch.cuda.synchronize()
+    return prefill_tokens / (time.perf_counter() - t0)
+
+
+def decode_roofline(engine, args):
+    """Average duration of the paged-decode launches of REAL decode steps of this run, measured with
+    HIP events on the launching stream: the executor is switched to eager for a few extra steps and
+    every mv_paged_decode launch (one per layer, in situ between the GEMMs, on the live block
+    tables / context lengths / KV cache) is bracketed by an event pair."""
+    from minivllm_amd import hip_ops
+    from minivllm_amd.layers import attention as attn_mod
+
+    ex = engine.model_runner.inference_executor
+    seqs = list(engine.scheduler.running)
+    lens = [len(s) for s in seqs]
+    L, nb, bs, hkv, d = ex.kv_cache.shape[1:]
+    heads = MODELS[args.model]["num_attention_heads"] // args.gpus
+    pairs = []
+    real = hip_ops.paged_decode
+
+    def timed(*a, **kw):
+        stream = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        out = real(*a, **kw)
+        e1.record(stream)
+        pairs.append((e0, e1))
+        return out
+    was_eager = ex.enforce_eager
+    ex.enforce_eager = True
+    try:
+        engine.step()                       # eager warm-up step (kernels already resident)
+        attn_mod.hip_ops.paged_decode = timed
+        probe_steps = 3
+        for _ in range(probe_steps):
+            engine.step()
+    finally:
+        attn_mod.hip_ops.paged_decode = real
+        ex.enforce_eager = was_eager
+    torch.cuda.synchronize()
+    assert len(pairs) == probe_steps * L
+    sec = sum(a.elapsed_time(b) for a, b in pairs) * 1e-3 / len(pairs)
+    esz = ex.dtype.itemsize
+    lens = [n + 1 + probe_steps // 2 for n in lens]   # context length at the middle probe step
+    algo = sum(lens) * 2 * hkv * d * esz + 2 * len(seqs) * heads * d * esz + sum(-(-n // bs) for n in lens) * 4
+    gbs = algo / sec / 1e9
+    return {"bound": "hbm", "kernel": "paged_decode_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "bytes_per_launch": algo, "us_per_launch": round(sec * 1e6, 2), "launches_timed": len(pairs)}
+
+
+def cpu_baseline(args):
+    """Oracle (CPU restatement of the reference's eager path) decode tokens/s, bounded sample."""
+    from oracle.model import OracleModel
+
+    cfg = MODELS[args.model]
+    b, ctx = 8, 128
+    nblk = -(-(ctx + 64) // 64)
+    t_build = time.perf_counter()
+    model = OracleModel.random(cfg, dtype=torch.bfloat16, num_blocks=b * nblk, block_size=64)
+    for kc, vc in zip(model.k_cache, model.v_cache):
+        kc.normal_()
+        vc.normal_()
+    tables = torch.arange(b * nblk, dtype=torch.int32).view(b, nblk)
+    lens = torch.full((b,), ctx, dtype=torch.int32)
+    ids = torch.randint(0, cfg["vocab_size"], (b,))
+    build_s = time.perf_counter() - t_build
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        pos = (lens - 1).long()
+        slots = (tables[torch.arange(b), (pos // 64)] * 64 + (pos % 64).int()).int()
+        meta = dict(is_prefill=False, slot_mapping=slots, block_tables=tables, context_lens=lens)
+        logits = model.forward_logits(ids, pos, meta)
+        ids = logits.float().argmax(-1)
+        lens = lens + 1
+        steps += 1
+        el = time.perf_counter() - t0
+        if (steps >= 2 and el > args.cpu_seconds) or steps >= 64:
+            break
+    return {"value": round(b * steps / el, 2), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{args.model} bf16 random weights, decode only, B={b}, ctx {ctx}->{ctx + steps}, "
+                      f"{steps} steps in {el:.1f}s on {os.cpu_count()} logical CPUs (oracle/model.py; build {build_s:.0f}s)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("TORCHELASTIC_RUN_ID", "bench")
+    import torch.distributed as dist
+
+    with tempfile.TemporaryDirectory() as workdir:
+        engine = build_engine(args, workdir)
+        prefill_tps = fill_prompts(engine, args)
+
+        def barrier():
+            torch.cuda.synchronize()
+            if args.gpus > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            engine.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            engine.step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if args.gpus > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert len(engine.scheduler.running) == args.batch, "a sequence finished inside the timed region"
+        roof = decode_roofline(engine, args)
+        ex = engine.model_runner.inference_executor
+        graphs = bool(ex.graphs)
+        kv_blocks = engine.config.num_kvcache_blocks
+        engine.exit()
+    if rank != 0:
+        return
+    cpu = None if args.no_cpu_baseline else cpu_baseline(args)
+    value = args.batch * args.steps / elapsed
+    line = {
+        "metric": "decode tokens/s", "value": round(value, 1), "unit": "tokens/s", "n_gpus": args.gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.model} decode, B={args.batch}, ctx={args.ctx}, kvcache_block_size=64, "
+                               f"max_num_seqs={args.batch}, {'hipGraph' if graphs else 'eager'} decode, greedy",
+                   "model": args.model, "global_batch": args.batch, "seq_len": args.ctx,
+                   "parallelism": f"tp{args.gpus}", "kv_blocks": kv_blocks,
+                   "prefill": "synthetic KV" if args.synthetic_kv else "engine prefill"},
+        "prefill_tokens_per_s": None if prefill_tps is None else round(prefill_tps, 1),
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
