@@ -262,6 +262,8 @@ PREFILL_CASES = [
     (7, 1, 128, [200, 33]),
     (4, 4, 64, [17, 90]),
     (16, 8, 128, [257]),
+    (8, 4, 128, [300, 1000, 129, 128, 127, 63, 65]),   # MFMA path: every tile / block edge
+    (2, 1, 128, [2048]),                               # long sequence, many KV tiles
 ]
 
 
@@ -278,6 +280,27 @@ def test_prefill_varlen_vs_oracle(H, case, dtype):
     ref = O.prefill_varlen(q, k, v, cu, cu, scale)
     out = H.prefill_varlen(q.to(DEV), k.to(DEV), v.to(DEV), cu.to(DEV), cu.to(DEV), max(lens), max(lens), scale)
     torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
+
+
+def test_prefill_mfma_strided_qkv_and_f16(H):
+    """q/k/v as views of one fused qkv buffer (the engine's layout), f16, and a rescale-forcing
+    input: one key per row with a huge score late in the sequence (online-softmax max jump)."""
+    Hq, Hkv, D, lens = 4, 2, 128, [190, 70]
+    T = sum(lens)
+    for dtype in (torch.float16, torch.bfloat16):
+        qkv = _randn(T, (Hq + 2 * Hkv) * D, dtype=dtype, seed=33)
+        q = qkv[:, :Hq * D].view(T, Hq, D)
+        k = qkv[:, Hq * D:(Hq + Hkv) * D].view(T, Hkv, D).clone()
+        v = qkv[:, (Hq + Hkv) * D:].view(T, Hkv, D)
+        k[150] = k[150] * 6.0     # spike: the running max jumps in the third KV tile
+        k[10] = k[10] * -5.0
+        cu = torch.tensor([0, lens[0], T], dtype=torch.int32)
+        ref = O.prefill_varlen(q, k, v, cu, cu, D ** -0.5)
+        qkv_d = qkv.to(DEV)
+        out = H.prefill_varlen(qkv_d[:, :Hq * D].view(T, Hq, D), k.to(DEV),
+                               qkv_d[:, (Hq + Hkv) * D:].view(T, Hkv, D), cu.to(DEV), cu.to(DEV),
+                               max(lens), max(lens), D ** -0.5)
+        torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
