@@ -1,0 +1,29 @@
+// Shared parameter block of the paged-decode kernels (K3).
+#pragma once
+#include "common.h"
+
+struct DecodeParams {
+  const void *q;
+  const void *k_cache;
+  const void *v_cache;
+  const int32_t *block_tables;
+  const int32_t *context_lens;
+  void *out;
+  float *ws_acc;  // [B, H, nsplit, D]
+  float *ws_ml;   // [B, H, nsplit, 2]
+  int64_t q_stride;
+  int64_t table_stride;
+  int64_t num_blocks;
+  int n_heads;
+  int n_kv_heads;
+  int g_total;   // q heads per kv head
+  int block_size;
+  int bs_shift;  // log2(block_size) or -1
+  int max_blocks;
+  int nsplit;
+  float scale_log2;  // softmax scale * log2(e)
+};
+
+// MFMA variant (16-bit dtypes, D = 128, >= 4 query heads per kv head); g_chunk <= 16 heads per workgroup
+int mv_paged_decode_mfma_launch(const DecodeParams &p, int n_chunks, int nsplit, int batch, int dtype,
+                                hipStream_t stream);

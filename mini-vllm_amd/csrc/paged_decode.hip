@@ -11,30 +11,9 @@
 // (no cross-lane traffic in the loop besides the in-row DPP dot-product
 // reduction); groups, waves and splits are merged at the end through
 // shuffles, LDS and (only when split) an fp32 workspace.
-#include "common.h"
+#include "paged_decode.h"
+#include <cstdlib>
 
-
-struct DecodeParams {
-  const void *q;
-  const void *k_cache;
-  const void *v_cache;
-  const int32_t *block_tables;
-  const int32_t *context_lens;
-  void *out;
-  float *ws_acc;  // [B, H, nsplit, D]
-  float *ws_ml;   // [B, H, nsplit, 2]
-  int64_t q_stride;
-  int64_t table_stride;
-  int64_t num_blocks;
-  int n_heads;
-  int n_kv_heads;
-  int g_total;   // q heads per kv head
-  int block_size;
-  int bs_shift;  // log2(block_size) or -1
-  int max_blocks;
-  int nsplit;
-  float scale_log2;  // softmax scale * log2(e)
-};
 
 template <typename Tag>
 __device__ __forceinline__ float dot16B(const u32x4 &a, const u32x4 &b) {
@@ -293,10 +272,12 @@ struct DecodePlan {
   int unit;
   int nsplit;
   bool uniform;
+  bool mfma;  // tensor-core variant (paged_decode_mfma.hip)
 };
 
 constexpr int kTargetWorkgroups = 2048;  // ~8 workgroups per CU
 constexpr int kMaxSplits = 64;
+constexpr int kMfmaMinGroup = 4;
 
 int pick_g(int g_total) {
   if (g_total <= 8) return g_total;
@@ -311,18 +292,36 @@ bool make_plan(int batch, int n_heads, int n_kv_heads, int head_dim, int block_s
   if (n_kv_heads <= 0 || n_heads % n_kv_heads) return false;
   if (head_dim != 64 && head_dim != 128) return false;
   const int g_total = n_heads / n_kv_heads;
-  pl->g_chunk = pick_g(g_total);
-  pl->n_chunks = (g_total + pl->g_chunk - 1) / pl->g_chunk;
-  const int vec = dtype == MV_F32 ? 4 : 8;
-  const int tpl = 64 / (head_dim / vec);
-  pl->nload = pl->g_chunk <= 4 ? 8 : 4;
-  pl->tile = pl->nload * tpl;
-  pl->unit = 4 * pl->tile;
-  pl->uniform = block_size % pl->tile == 0;
+  // >= 4 query heads per kv head: QK^T and PV go to the matrix cores (the vector path spends
+  // ~G x 20 VALU instructions per key and drops to 2-3.7 TB/s at G = 7..8)
+  static const int min_group = [] {  // MV_DECODE_MFMA_MIN_G: tuning override (1 = always, 99 = never)
+    const char *e = getenv("MV_DECODE_MFMA_MIN_G");
+    return e ? atoi(e) : kMfmaMinGroup;
+  }();
+  pl->mfma = dtype != MV_F32 && head_dim == 128 && g_total >= min_group && block_size % 32 == 0;
+  if (pl->mfma) {
+    pl->g_chunk = g_total < 16 ? g_total : 16;
+    pl->n_chunks = (g_total + 15) / 16;
+    pl->nload = 8;
+    pl->tile = 32;
+    pl->unit = 128;
+    pl->uniform = true;
+  } else {
+    pl->g_chunk = pick_g(g_total);
+    pl->n_chunks = (g_total + pl->g_chunk - 1) / pl->g_chunk;
+    const int vec = dtype == MV_F32 ? 4 : 8;
+    const int tpl = 64 / (head_dim / vec);
+    pl->nload = pl->g_chunk <= 4 ? 8 : 4;
+    pl->tile = pl->nload * tpl;
+    pl->unit = 4 * pl->tile;
+    pl->uniform = block_size % pl->tile == 0;
+  }
   const int64_t max_ctx = (int64_t)max_blocks * block_size;
   const int max_units = (int)((max_ctx + pl->unit - 1) / pl->unit);
   const int64_t wg = (int64_t)batch * n_kv_heads * pl->n_chunks;
-  int ns = wg > 0 ? (int)((kTargetWorkgroups + wg - 1) / wg) : 1;
+  // the matrix-core kernel keeps 4 workgroups per CU resident (LDS): one wave of 1024 is enough
+  const int target = pl->mfma ? kTargetWorkgroups / 2 : kTargetWorkgroups;
+  int ns = wg > 0 ? (int)((target + wg - 1) / wg) : 1;
   if (ns > max_units) ns = max_units;
   if (ns > kMaxSplits) ns = kMaxSplits;
   if (ns < 1) ns = 1;
@@ -342,7 +341,17 @@ void launch_g(const DecodeParams &p, const DecodePlan &pl, int batch, hipStream_
 }
 
 template <typename Tag, int D>
-int launch_d(const DecodeParams &p, const DecodePlan &pl, int batch, hipStream_t stream) {
+int launch_d(const DecodeParams &p, const DecodePlan &pl, int batch, int dtype, hipStream_t stream) {
+  if (pl.mfma) {
+    const int rc = mv_paged_decode_mfma_launch(p, pl.n_chunks, pl.nsplit, batch, dtype, stream);
+    if (rc != MV_OK) return rc;
+    if (pl.nsplit > 1) {
+      hipLaunchKernelGGL((paged_decode_reduce_kernel<Tag, D>), dim3(batch * p.n_heads), dim3(D), 0,
+                         stream, p.ws_acc, p.ws_ml, (typename elem<Tag>::T *)p.out, pl.nsplit);
+      MV_LAUNCH_CHECK();
+    }
+    return MV_OK;
+  }
   switch (pl.g_chunk) {
     case 1: launch_g<Tag, D, 1, 8>(p, pl, batch, stream); break;
     case 2: launch_g<Tag, D, 2, 8>(p, pl, batch, stream); break;
@@ -434,9 +443,9 @@ extern "C" int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *
   }
   hipStream_t st = (hipStream_t)stream;
   if (head_dim == 128) {
-    MV_DISPATCH_DTYPE(dtype, return (launch_d<Tag, 128>(p, pl, batch, st)));
+    MV_DISPATCH_DTYPE(dtype, return (launch_d<Tag, 128>(p, pl, batch, dtype, st)));
   } else {
-    MV_DISPATCH_DTYPE(dtype, return (launch_d<Tag, 64>(p, pl, batch, st)));
+    MV_DISPATCH_DTYPE(dtype, return (launch_d<Tag, 64>(p, pl, batch, dtype, st)));
   }
   return MV_OK;
 }

@@ -49,7 +49,7 @@ class DistributedManager:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             kw = {}
             if self.backend == "nccl":
-                local = int(os.environ.get("LOCAL_RANK", self.rank))
+                local = int(os.environ.get("LOCAL_RANK", self.rank)) % torch.cuda.device_count()
                 torch.cuda.set_device(local)
                 kw["device_id"] = torch.device("cuda", local)
             try:

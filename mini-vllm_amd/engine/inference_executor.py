@@ -107,6 +107,13 @@ class InferenceExecutor:
                                f"Available: {avail} bytes, Block size: {block_bytes} bytes")
         cap = cfg.max_num_seqs * self.max_blocks_per_seq
         n = min(avail // block_bytes, cap)
+        if get_tensor_parallel_world_size() > 1:
+            # every rank runs the same scheduler: they must agree on the pool size
+            import torch.distributed as dist
+
+            t = torch.tensor([n], dtype=torch.int64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            n = int(t.item())
         if n <= 0:
             raise ValueError(f"Calculated KV cache blocks ({n}) must be > 0. Available memory: {avail} bytes, "
                              f"Block size: {block_bytes} bytes")
@@ -261,6 +268,13 @@ class InferenceExecutor:
         """Capture one hipGraph per decode batch-size bucket (largest first, shared pool)."""
         if self.enforce_eager:
             return
+        if get_tensor_parallel_world_size() > 1:
+            import torch.distributed as dist
+
+            if dist.get_backend() != "nccl":
+                # only RCCL collectives can be captured; a failed capture cannot be recovered from
+                logger.warning("tensor-parallel backend %s is not capturable: decoding eagerly", dist.get_backend())
+                return
         self.graph_bs = graph_batch_sizes(min(max_batch_size, self.config.max_num_seqs))
         max_bs = self.graph_bs[-1]
         hidden = self.config.hf_config.hidden_size
@@ -288,10 +302,18 @@ class InferenceExecutor:
             logger.info("Captured %d decode graphs (batch sizes %s..%d)", len(self.graphs),
                         self.graph_bs[:4], self.graph_bs[-1])
         except Exception as e:  # fall back to eager, loudly
-            logger.warning("Failed to capture device graphs: %s", e)
+            logger.warning("Failed to capture device graphs, decoding eagerly: %s", e)
             self.graphs.clear()
+            self.graph_pool = None
             self.sampler.offset_dev = None
             reset_context()
+            # a failed capture leaves torch's side capture stream current (torch.cuda.graph.__exit__
+            # raises in capture_end before restoring it): go back to the default stream
+            torch.cuda.set_stream(torch.cuda.default_stream(self.device))
+            try:
+                torch.cuda.synchronize(self.device)
+            except Exception:  # the invalidated capture reports once more; the device itself is fine
+                pass
 
     def _graph_forward(self, bs: int):
         gv = self.graph_vars

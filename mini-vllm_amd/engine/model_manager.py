@@ -50,7 +50,8 @@ class ModelManager:
         if not torch.cuda.is_available():
             raise RuntimeError("minivllm_amd needs a ROCm GPU (MI355X): the inference hot path runs on "
                                "hand-written HIP kernels and has no CPU fallback")
-        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # one process per GPU; modulo only matters when ranks outnumber GPUs (single-GPU TP tests)
+        local_rank = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
         self.device = torch.device("cuda", local_rank)
         torch.cuda.set_device(self.device)
 

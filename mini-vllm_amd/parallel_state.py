@@ -46,8 +46,16 @@ def tp_all_gather_last_dim(x: torch.Tensor) -> torch.Tensor:
     n = _state["size"]
     if n == 1:
         return x
-    out = torch.empty((n,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x.contiguous(), group=_state["group"])
+    if x.is_cuda and dist.get_backend(_state["group"]) == "gloo":
+        # gloo has no device all-gather; only the 2-process single-GPU TP test takes this path
+        out = torch.zeros((n,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        out[_state["rank"]] = x
+        dist.all_reduce(out, group=_state["group"])
+    else:
+        x = x.contiguous()
+        flat = torch.empty((n * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(flat, x, group=_state["group"])  # rank-major along dim 0
+        out = flat.view((n,) + tuple(x.shape))
     return out.movedim(0, -2).reshape(*x.shape[:-1], n * x.shape[-1])
 
 

@@ -95,6 +95,9 @@ DECODE_CASES = [
     (2, 32, 2, 128, 64, [257, 31]),             # G = 16 -> two head chunks
     (1, 16, 8, 128, 64, [4096]),                # long context, split-KV
     (5, 4, 2, 64, 4, [1, 2, 3, 9, 40]),         # tiny blocks, generic (non-uniform) path
+    (3, 16, 4, 128, 64, [31, 32, 33]),          # G = 4: smallest matrix-core group, tile edges
+    (2, 40, 2, 128, 64, [500, 129]),            # G = 20: two head chunks, ragged second chunk
+    (2, 28, 4, 128, 32, [100, 2000]),           # G = 7 with 32-token blocks, split-KV
 ]
 
 

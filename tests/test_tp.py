@@ -1,0 +1,180 @@
+"""Tensor parallelism (SURVEY §8 a13 / e).  The reference never exercises TP>1 (its layers are built
+before the process group exists), so the oracle here is the build's own TP=1 result
+and, end to end, the reference's TP=1 logits.
+  * CPU, gloo, world_size 2: sharded linears / embedding / LM head == unsharded math
+  * GPU, 2 processes on the one card (gloo for the collectives): tiny Qwen3 with TP=2 reproduces the
+    reference logits."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _init(rank, world, port):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_grad_enabled(False)      # inference only, like the engine (torch.inference_mode)
+    from minivllm_amd import parallel_state
+
+    parallel_state.init_tensor_parallel(rank, world)
+
+
+def _layers_worker(rank, world, port, out_path):
+    _init(rank, world, port)
+    import torch.nn.functional as F
+
+    from minivllm_amd.layers.embed_head import ParallelLMHead, VocabParallelEmbedding
+    from minivllm_amd.layers.linear import (ColumnParallelLinear, MergedColumnParallelLinear, QKVParallelLinear,
+                                            RowParallelLinear)
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 64, generator=g)
+    res = {}
+    # column -> row (the MLP / attention-output pattern): one all-reduce restores the full product
+    wc, bc = torch.randn(96, 64, generator=g), torch.randn(96, generator=g)
+    wr, br = torch.randn(64, 96, generator=g), torch.randn(64, generator=g)
+    col, row = ColumnParallelLinear(64, 96, bias=True), RowParallelLinear(96, 64, bias=True)
+    col.weight.weight_loader(col.weight, wc); col.bias.weight_loader(col.bias, bc)
+    row.weight.weight_loader(row.weight, wr); row.bias.data.zero_(); row.bias.weight_loader(row.bias, br)
+    assert col.weight.shape == (96 // world, 64) and row.weight.shape == (64, 96 // world)
+    res["mlp"] = (row(col(x)), F.linear(F.linear(x, wc, bc), wr, br))
+    # merged gate|up: each rank holds its slice of BOTH halves
+    wg, wu = torch.randn(32, 64, generator=g), torch.randn(32, 64, generator=g)
+    mc = MergedColumnParallelLinear(64, [32, 32])
+    mc.weight.weight_loader(mc.weight, wg, 0); mc.weight.weight_loader(mc.weight, wu, 1)
+    y = mc(x)
+    h = 32 // world
+    assert torch.equal(y[:, :h], F.linear(x, wg[rank * h:(rank + 1) * h]))
+    assert torch.equal(y[:, h:], F.linear(x, wu[rank * h:(rank + 1) * h]))
+    # fused qkv: rank r owns q heads and kv heads r*n/tp .. ; layout [q_r | k_r | v_r]
+    hd, H, Hkv = 16, 4, 2
+    wq, wk, wv = (torch.randn(n * hd, 64, generator=g) for n in (H, Hkv, Hkv))
+    qkv = QKVParallelLinear(64, hd, H, Hkv)
+    for w, sid in ((wq, "q"), (wk, "k"), (wv, "v")):
+        qkv.weight.weight_loader(qkv.weight, w, sid)
+    y = qkv(x)
+    qs, ks = H * hd // world, Hkv * hd // world
+    assert torch.equal(y[:, :qs], F.linear(x, wq[rank * qs:(rank + 1) * qs]))
+    assert torch.equal(y[:, qs:qs + ks], F.linear(x, wk[rank * ks:(rank + 1) * ks]))
+    assert torch.equal(y[:, qs + ks:], F.linear(x, wv[rank * ks:(rank + 1) * ks]))
+    # vocab-parallel embedding (masked lookup + all-reduce) and LM head (all ranks get all logits)
+    table = torch.randn(40, 64, generator=g)
+    emb, head = VocabParallelEmbedding(40, 64), ParallelLMHead(40, 64)
+    emb.weight.weight_loader(emb.weight, table); head.weight.weight_loader(head.weight, table)
+    ids = torch.tensor([0, 39, 20, 19, 7])
+    res["emb"] = (emb(ids), F.embedding(ids, table))
+    res["head"] = (head(x), F.linear(x, table))
+    with pytest.raises(ValueError):
+        VocabParallelEmbedding(41, 8)
+    with pytest.raises(ValueError):
+        ColumnParallelLinear(8, 7)
+    for k, (got, want) in res.items():
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5, msg=k)
+    dist.barrier()
+    if rank == 0:
+        open(out_path, "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_tp2_layers_cpu_gloo(tmp_path):
+    out = str(tmp_path / "ok")
+    mp.spawn(_layers_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def _qwen_heads_rule_worker(rank, world, port, out_path):
+    _init(rank, world, port)
+    from types import SimpleNamespace
+
+    # Qwen2-7B has 28 q heads / 4 kv heads: TP=8 is rejected (here with world 2 and 3 kv heads)
+    ok = False
+    try:
+        from minivllm_amd.layers.linear import QKVParallelLinear
+
+        QKVParallelLinear(64, 16, 4, 3)
+    except ValueError:
+        ok = True
+    dist.barrier()
+    if rank == 0:
+        open(out_path, "w").write("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+def test_indivisible_heads_rejected(tmp_path):
+    out = str(tmp_path / "ok")
+    mp.spawn(_qwen_heads_rule_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+# ---------------------------------------------------------------------------------- GPU, TP = 2
+def _e2e_worker(rank, world, port, golden, workdir, out_path):
+    os.environ["MINIVLLM_TP_BACKEND"] = "gloo"
+    os.environ["LOCAL_RANK"] = "0"                      # both ranks share the single GPU of the box
+    _init(rank, world, port)
+    torch.cuda.set_device(0)
+    from minivllm_amd.config import Config
+    from minivllm_amd.engine.block_manager import BlockManager
+    from minivllm_amd.engine.inference_executor import InferenceExecutor
+    from minivllm_amd.engine.sequence import Sequence
+    from minivllm_amd.glue import create_model
+
+    z = np.load(golden)
+    cfg = Config(workdir, num_kvcache_blocks=16, max_model_len=512, max_num_batched_tokens=1024, max_num_seqs=8,
+                 enforce_eager=True, dtype="float32", tensor_parallel_size=world)
+    with torch.device("cuda:0"):
+        model = create_model(cfg.hf_config)
+    weights = {k[2:]: torch.from_numpy(z[k].view(np.int16).copy()).view(torch.bfloat16).float()
+               for k in z.files if k.startswith("w:")}
+    model.load_weights(weights)                         # every weight_loader slices its own shard
+    attn = model.model.layers[0].self_attn
+    assert (attn.num_heads, attn.num_kv_heads) == (2, 1)
+    ex = InferenceExecutor(cfg, model.to("cuda:0"), torch.device("cuda:0"))
+    assert ex.num_kv_heads == 1                         # KV cache sized with LOCAL kv heads
+    ex._allocate_kv_cache(); ex._initialize_sampler(); ex._optimize_model()
+    lens, flat = z["prompt_lens"].tolist(), z["prompts"].tolist()
+    prompts, o = [], 0
+    for n in lens:
+        prompts.append(flat[o:o + n]); o += n
+    bm = BlockManager(16, 64)
+    seqs = [Sequence(p, block_size=64) for p in prompts]
+    for s in seqs:
+        bm.allocate(s)
+    logits, _ = ex.execute_batch(seqs, prefill=True)
+    errs = [(logits.float().cpu() - torch.from_numpy(z["f32_prefill_logits"])).abs().max().item()]
+    for step in range(int(z["n_decode"])):
+        for s, t in zip(seqs, z["forced_tokens"][step].tolist()):
+            s.append_token(int(t)); bm.may_append(s)
+        logits, _ = ex.execute_batch(seqs, prefill=False)
+        errs.append((logits.float().cpu() - torch.from_numpy(z[f"f32_decode_logits_{step}"])).abs().max().item())
+    scale = float(np.abs(z["f32_prefill_logits"]).max())
+    dist.barrier()
+    open(out_path + f".{rank}", "w").write(json.dumps(dict(errs=errs, scale=scale)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_tp2_logits_match_reference_on_one_gpu(golden_dir, tmp_path):
+    golden = os.path.join(golden_dir, "e2e_qwen3.npz")
+    z = np.load(golden)
+    (tmp_path / "config.json").write_text(bytes(z["config_json"]).decode())
+    out = str(tmp_path / "res")
+    mp.spawn(_e2e_worker, args=(2, _free_port(), golden, str(tmp_path), out), nprocs=2, join=True)
+    for rank in (0, 1):                                 # SPMD: every rank holds the full logits
+        r = json.loads(open(out + f".{rank}").read())
+        assert max(r["errs"]) <= 2e-4 * r["scale"], r
