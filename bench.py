@@ -149,8 +149,18 @@ def decode_roofline(engine, args):
     lens = [n + 1 + probe_steps // 2 for n in lens]   # context length at the middle probe step
     algo = sum(lens) * 2 * hkv * d * esz + 2 * len(seqs) * heads * d * esz + sum(-(-n // bs) for n in lens) * 4
     gbs = algo / sec / 1e9
+    # HBM traffic from the PMC counters (separate rocprofv3 --pmc passes, corrected as the microarch guide
+    # prescribes): measured on the same kernel / head layout at B=256, ctx=1024 and scaled by bytes
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_decode.json")
+    if os.path.exists(pmc) and args.gpus == 1:
+        with open(pmc) as f:
+            for name, rec in json.load(f)["kernels"].items():
+                if args.model in name:
+                    traffic = int(algo * rec["ratio"])
     return {"bound": "hbm", "kernel": "paged_decode_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": "profiles/r01_pmc_decode.json (PMC FETCH_SIZE x2 + WRITE_SIZE, per launch, scaled to this run's context)" if traffic else None,
             "bytes_per_launch": algo, "us_per_launch": round(sec * 1e6, 2), "launches_timed": len(pairs)}
 
 
@@ -162,7 +172,7 @@ def cpu_baseline(args):
     b, ctx = 8, 128
     nblk = -(-(ctx + 64) // 64)
     t_build = time.perf_counter()
-    model = OracleModel.random(cfg, dtype=torch.bfloat16, num_blocks=b * nblk, block_size=64)
+    model = OracleModel.random(cfg, dtype=torch.float32, num_blocks=b * nblk, block_size=64)
     for kc, vc in zip(model.k_cache, model.v_cache):
         kc.normal_()
         vc.normal_()
@@ -183,7 +193,7 @@ def cpu_baseline(args):
         if (steps >= 2 and el > args.cpu_seconds) or steps >= 64:
             break
     return {"value": round(b * steps / el, 2), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{args.model} bf16 random weights, decode only, B={b}, ctx {ctx}->{ctx + steps}, "
+            "sample": f"{args.model} fp32 (the reference's CPU dtype, examples/cpu_inference_opt.py:143-151) random weights, decode only, B={b}, ctx {ctx}->{ctx + steps}, "
                       f"{steps} steps in {el:.1f}s on {os.cpu_count()} logical CPUs (oracle/model.py; build {build_s:.0f}s)"}
 
 
