@@ -132,6 +132,8 @@ __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
       if (blk >= 0 && blk < p.num_blocks)
         uni_row = (int64_t)blk * p.block_size + (tile_base - bi * p.block_size);
     }
+    // Loads are unconditional: a token past the context (or in a hole of the table) re-reads the
+    // sequence's token 0 / the tile's first token — finite data, masked to probability 0 below.
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       const int tok = tile_base + i * TPL + grp;
@@ -139,18 +141,19 @@ __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
       bool ok = tok < ctx;
       if constexpr (UNIFORM) {
         ok = ok && uni_row >= 0;
-        row = uni_row + i * TPL + grp;
+        row = (uni_row >= 0 ? uni_row : 0) + (ok ? i * TPL + grp : 0);
       } else {
-        const int bi = p.bs_shift >= 0 ? (tok >> p.bs_shift) : (tok / p.block_size);
-        int blk = -1;
-        if (ok && bi < p.max_blocks) blk = table[bi];
-        ok = ok && blk >= 0 && blk < p.num_blocks;
-        row = (int64_t)blk * p.block_size + (tok - bi * p.block_size);
+        const int tk = ok ? tok : tile_base;  // tile_base < ctx
+        const int bi = p.bs_shift >= 0 ? (tk >> p.bs_shift) : (tk / p.block_size);
+        const int blk = bi < p.max_blocks ? table[bi] : -1;
+        const bool blk_ok = blk >= 0 && blk < p.num_blocks;
+        ok = ok && blk_ok;
+        row = blk_ok ? (int64_t)blk * p.block_size + (tk - bi * p.block_size) : 0;
       }
       valid[i] = ok;
-      const u32x4 zero = {0u, 0u, 0u, 0u};
-      kraw[i] = ok ? *reinterpret_cast<const u32x4 *>(kbase + row * row_stride) : zero;
-      vraw[i] = ok ? *reinterpret_cast<const u32x4 *>(vbase + row * row_stride) : zero;
+      kraw[i] = *reinterpret_cast<const u32x4 *>(kbase + row * row_stride);
+      vraw[i] = *reinterpret_cast<const u32x4 *>(vbase + row * row_stride);
+      if (!ok) vraw[i] = u32x4{0u, 0u, 0u, 0u};  // row 0 of a foreign block may hold anything (0 * NaN)
     }
 
     // scores (log2 domain) + online softmax, per query head

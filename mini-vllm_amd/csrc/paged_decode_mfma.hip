@@ -41,7 +41,11 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4 &a, const u32x4 &b, const f3
 
 template <typename Tag>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return (uint32_t)elem<Tag>::st(lo) | ((uint32_t)elem<Tag>::st(hi) << 16);
+  // one v_cvt_pk_{bf16,f16}_f32 (round to nearest even), not two converts + a merge
+  if constexpr (__is_same(Tag, bf16_tag))
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t));
+  else
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2_t));
 }
 
 // LDS row of key kk (0..31) of a tile: the four 4-key blocks of a 16-key half are placed so that the
@@ -107,7 +111,6 @@ __global__ void __launch_bounds__(256, 4) paged_decode_mfma_kernel(DecodeParams 
     const int64_t row0 = (int64_t)blk * p.block_size + (tile_base - bi * p.block_size);
     const T *kb = (const T *)p.k_cache + (row0 * p.n_kv_heads + hkv) * D;
     const T *vb = (const T *)p.v_cache + (row0 * p.n_kv_heads + hkv) * D;
-    const u32x4 zero = {0u, 0u, 0u, 0u};
 
     // ---- V: LDS-DMA (global_load_lds_dwordx4), no VGPR staging.  Instruction n fills LDS rows
     //      4n..4n+3 linearly (wave base + lane*16), so the swizzle goes on the SOURCE: lane (quad, i16)
@@ -129,11 +132,10 @@ __global__ void __launch_bounds__(256, 4) paged_decode_mfma_kernel(DecodeParams 
     u32x4 kf[2][4];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      const int kk = 16 * kt + i16;
-      const bool ok = blk_ok && (tile_base + kk) < ctx;
+      const int kk = min(16 * kt + i16, n_valid - 1);  // past the context: re-read a valid key (masked below)
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        kf[kt][s] = ok ? *reinterpret_cast<const u32x4 *>(kb + kk * row_elems + 32 * s + 8 * quad) : zero;
+        kf[kt][s] = *reinterpret_cast<const u32x4 *>(kb + kk * row_elems + 32 * s + 8 * quad);
     }
     // (K loads are issued AFTER the V DMA below: vmcnt retires in order, so "K has landed" implies
     //  "V is in LDS")
@@ -189,11 +191,9 @@ __global__ void __launch_bounds__(256, 4) paged_decode_mfma_kernel(DecodeParams 
       const int ch = 2 * dt + (pp >> 1);
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(vlds + v_off(lrow_a, ch) + 8 * (pp & 1)));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(vlds + v_off(lrow_a + 16, ch) + 8 * (pp & 1)));
-      u32x4 a;
-      a[0] = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
-      a[1] = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
-      a[2] = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
-      a[3] = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+      // the transposed read already delivers packed 16-bit pairs: reinterpret, do not repack
+      const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+      const u32x4 a = {lo2.x, lo2.y, hi2.x, hi2.y};
       oacc[dt] = mfma16<Tag>(a, pf, oacc[dt]);
     }
   }

@@ -40,7 +40,11 @@ __device__ __forceinline__ f32x16 mfma(const u32x4 &a, const u32x4 &b, const f32
 
 template <typename Tag>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return (uint32_t)elem<Tag>::st(lo) | ((uint32_t)elem<Tag>::st(hi) << 16);
+  // one v_cvt_pk_{bf16,f16}_f32 (round to nearest even), not two converts + a merge
+  if constexpr (__is_same(Tag, bf16_tag))
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t));
+  else
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2_t));
 }
 
 // K tile: row-major [key][D], 16-byte chunk index XORed with (key & 15): the A-operand read
@@ -64,9 +68,12 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
   const int r = lane & 31, h = lane >> 5;
   const int g = (lane >> 4) & 1, i16 = lane & 15;
 
-  const int seq = blockIdx.z, head = blockIdx.y;
-  // heaviest (latest) query blocks first: the causal tail finishes earlier
-  const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+  // Dispatch order is x fastest, z slowest: the query block is the SLOWEST index and runs from the
+  // heaviest (latest rows, most KV tiles) to the lightest, across all heads and sequences — otherwise
+  // the last (head, sequence) pair starts its 64-tile blocks when everything else has drained
+  // (measured: 0.92 resident waves per SIMD on average instead of 2).
+  const int head = blockIdx.x, seq = blockIdx.y;
+  const int qb = (int)gridDim.z - 1 - (int)blockIdx.z;
   const int q0 = p.cu_q[seq], sq = p.cu_q[seq + 1] - q0;
   const int k0 = p.cu_k[seq], sk = p.cu_k[seq + 1] - k0;
   if (qb * BM >= sq) return;
@@ -100,34 +107,33 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
   const int n_tiles = (kv_len + BN - 1) / BN;
   const int wave_qpos_min = shift + qb * BM + wave * 32;  // smallest key limit among this wave's rows
 
-  // ---- tile staging: each thread moves 4 x 16 B of K and of V per tile
+  // ---- tile staging: each thread moves 4 x 16 B of K and of V per tile.  Loads are unconditional
+  //      (a predicated load becomes an exec-masked branch per load): rows past the sequence end
+  //      re-read the last valid key — finite data whose probability is exactly 0 after masking.
+  const bool paged = p.block_tables != nullptr;
+  const T *ksrc = paged ? (const T *)p.k_cache : (const T *)p.k;
+  const T *vsrc = paged ? (const T *)p.v_cache : (const T *)p.v;
+  const int64_t kstride = paged ? (int64_t)p.n_kv_heads * D : p.k_stride;
+  const int64_t vstride = paged ? (int64_t)p.n_kv_heads * D : p.v_stride;
   u32x4 kreg[4], vreg[4];
+  bool tile_ok_next = true;
   auto fetch = [&](int t) {
     const int kv0 = t * BN;
-    int64_t base_row;  // row index into the K/V source of key kv0
-    bool tile_ok = true;
-    if (p.block_tables) {
+    int64_t base_row = k0 + kv0;  // row index into the K/V source of key kv0
+    tile_ok_next = true;
+    if (paged) {
       const int bi = kv0 / p.block_size;
       const int blk = p.block_tables[(int64_t)seq * p.table_stride + bi];
-      tile_ok = blk >= 0 && blk < p.num_blocks;
-      base_row = (int64_t)blk * p.block_size + (kv0 - bi * p.block_size);
-    } else {
-      base_row = k0 + kv0;
+      tile_ok_next = blk >= 0 && blk < p.num_blocks;  // a hole: read block 0, mask the whole tile
+      base_row = (int64_t)(tile_ok_next ? blk : 0) * p.block_size + (kv0 - bi * p.block_size);
     }
+    const int last = sk - 1 - kv0;  // last valid row of this tile (>= 0: the tile starts inside the sequence)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pc = tid + 256 * i;
-      const int row = pc >> 4, ch = pc & 15;
-      const bool ok = tile_ok && (kv0 + row) < sk;
-      const u32x4 zero = {0u, 0u, 0u, 0u};
-      if (p.block_tables) {
-        const int64_t e = ((base_row + row) * p.n_kv_heads + hkv) * D + ch * 8;
-        kreg[i] = ok ? *reinterpret_cast<const u32x4 *>((const T *)p.k_cache + e) : zero;
-        vreg[i] = ok ? *reinterpret_cast<const u32x4 *>((const T *)p.v_cache + e) : zero;
-      } else {
-        kreg[i] = ok ? *reinterpret_cast<const u32x4 *>((const T *)p.k + (base_row + row) * p.k_stride + hkv * D + ch * 8) : zero;
-        vreg[i] = ok ? *reinterpret_cast<const u32x4 *>((const T *)p.v + (base_row + row) * p.v_stride + hkv * D + ch * 8) : zero;
-      }
+      const int row = min(pc >> 4, last), ch = pc & 15;
+      kreg[i] = *reinterpret_cast<const u32x4 *>(ksrc + (base_row + row) * kstride + hkv * D + ch * 8);
+      vreg[i] = *reinterpret_cast<const u32x4 *>(vsrc + (base_row + row) * vstride + hkv * D + ch * 8);
     }
   };
   auto stage = [&]() {
@@ -145,57 +151,63 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
     __syncthreads();  // every wave is done reading the previous tile
     stage();
     __syncthreads();
+    const bool tile_ok = tile_ok_next;
     if (t + 1 < n_tiles) fetch(t + 1);  // in flight during this tile's MFMAs
     const int kv0 = t * BN;
 
-    // ---- S^T = K Q^T : two 32-key tiles
+    // ---- S^T = K Q^T : two 32-key tiles (raw, unscaled scores; first k-step starts from an inline 0)
     f32x16 sacc[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[kt][i] = 0.f;
       const int krow = kt * 32 + r;
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      sacc[kt] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(ldsK + k_off(krow, h)), qf[0], zero16);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
+      for (int s = 1; s < NS; ++s) {
         const u32x4 a = *reinterpret_cast<const u32x4 *>(ldsK + k_off(krow, 2 * s + h));
         sacc[kt] = mfma<Tag>(a, qf[s], sacc[kt]);
       }
     }
 
-    // ---- scale, mask, online softmax (log2 domain)
-    const bool need_mask = (kv0 + BN - 1 > wave_qpos_min) || (kv0 + BN > sk);
-    const int klim = min(qidx + shift, sk - 1);  // last key this query row may see
+    // ---- mask (only tiles that touch the diagonal / the ragged end: wave-uniform branch)
+    if ((kv0 + BN - 1 > wave_qpos_min) || (kv0 + BN > sk) || !tile_ok) {
+      const int klim = tile_ok ? min(qidx + shift, sk - 1) : -1;  // last key this query row may see
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = kv0 + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          sacc[kt][i] = key <= klim ? sacc[kt][i] : -INFINITY;
+        }
+    }
+    // ---- online softmax in the log2 domain: p = exp2(s*c - m), one FMA + one exp per score
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float s = sacc[kt][i] * scale_log2;
-        if (need_mask) {
-          const int key = kv0 + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          s = key <= klim ? s : -INFINITY;
-        }
-        sacc[kt][i] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kt][i]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    const float m_new = fmaxf(m_run, mx * scale_log2);  // scale > 0: max commutes with the scaling
+    if (!__all(m_new == m_run)) {  // some row's maximum moved: rescale (skipped on most tiles)
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+    }
+    const float neg_m = -m_run;
     float rs = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float e = __builtin_amdgcn_exp2f(sacc[kt][i] - m_new);
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][i], scale_log2, neg_m));
         sacc[kt][i] = e;
         rs += e;
       }
-    l_run = l_run * alpha + rs;
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+    l_run += rs;
 
     // ---- P^T as MFMA B operand: registers 8*s2 .. 8*s2+7 of a 32-key tile are k-step s2
     u32x4 pf[2][2];
@@ -221,11 +233,9 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
               (lds_s16x4 *)(ldsV + v_off(rb, ch) + 8 * (pp & 1)));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (lds_s16x4 *)(ldsV + v_off(rb + 8, ch) + 8 * (pp & 1)));
-          u32x4 a;
-          a[0] = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
-          a[1] = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
-          a[2] = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
-          a[3] = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+          // the transposed read already delivers packed 16-bit pairs: reinterpret, do not repack
+          const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+          const u32x4 a = {lo2.x, lo2.y, hi2.x, hi2.y};
           oacc[dt] = mfma<Tag>(a, pf[kt][s2], oacc[dt]);
         }
     }
@@ -255,7 +265,7 @@ int mv_prefill_mfma_launch(const PrefillParams &p, int dtype, hipStream_t stream
   if (p.block_tables && (p.block_size % BN) != 0) return MV_E_SHAPE;  // a 64-key tile must sit in one block
   const int q_blocks = (p.max_seqlen_q + BM - 1) / BM;
   if (q_blocks == 0 || p.n_seqs == 0) return MV_OK;
-  dim3 grid(q_blocks, p.n_heads, p.n_seqs), block(256);
+  dim3 grid(p.n_heads, p.n_seqs, q_blocks), block(256);
   const size_t lds = 2 * TILE_BYTES;
   if (dtype == MV_BF16)
     hipLaunchKernelGGL((prefill_mfma_kernel<bf16_tag>), grid, block, lds, stream, p);
