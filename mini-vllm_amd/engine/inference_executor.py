@@ -72,11 +72,17 @@ class InferenceExecutor:
         self.builder = InputBuilder(self.block_size, config.max_num_seqs, config.max_model_len,
                                     config.max_num_batched_tokens, pin_memory=self.device.type == "cuda")
         ms = config.max_num_seqs
-        # device mirrors of the decode staging buffers (allocated once; inference_executor.py:149-180)
-        self._dev_i64 = torch.zeros((2, ms), dtype=torch.int64, device=self.device)
-        self._dev_slots = torch.zeros(ms, dtype=torch.int32, device=self.device)
-        self._dev_ctx = torch.zeros(ms, dtype=torch.int32, device=self.device)
+        # device mirror of the builder's decode pack (ids | positions | slots | context_lens | rng): the whole
+        # per-step integer state arrives with ONE async copy; the typed views below alias it
+        b_ = self.builder
+        self._pack_dev = torch.zeros(b_.pack_nbytes, dtype=torch.uint8, device=self.device)
+        self._dev_ids = b_.pack_view(self._pack_dev, "ids")
+        self._dev_pos = b_.pack_view(self._pack_dev, "pos")
+        self._dev_slots = b_.pack_view(self._pack_dev, "slots")
+        self._dev_ctx = b_.pack_view(self._pack_dev, "ctx")
+        self._dev_rng = b_.pack_view(self._pack_dev, "rng")
         self._dev_tables = torch.full((ms, self.max_blocks_per_seq), -1, dtype=torch.int32, device=self.device)
+        self._samp_rows = -1  # rows of the device sampling planes that are current (-1: stale)
         # sampling parameters: one pinned plane, one device plane  [temps | top_ps | min_ps] f32, top_ks i64
         pin = self.device.type == "cuda"
         self._samp_f32 = torch.zeros((3, ms), dtype=torch.float32, pin_memory=pin)
@@ -178,9 +184,9 @@ class InferenceExecutor:
                 logits = self.model.compute_logits(self.model(ids, pos))
                 tokens = self._sample_tokens(logits, sequences)
             else:
-                inp = self.builder.decode(sequences)
                 bs = self._graph_bucket(len(sequences))
-                if bs is not None:
+                inp = self.builder.decode(sequences, pad_to=bs)
+                if bs is not None and inp.packed:
                     logits, tokens = self._replay_graph(bs, inp, sequences)
                 else:
                     ids, pos = self._ship_decode(inp)
@@ -204,27 +210,31 @@ class InferenceExecutor:
 
     def _ship_decode(self, inp: BatchInputs):
         b = inp.num_seqs
-        if b > self._dev_slots.shape[0]:  # oversize batch: one-off tensors
+        if not inp.packed:  # oversize batch: one-off tensors (inference_executor.py:687-688)
             set_context(False, 0, 0, None, None, self._to_dev(inp.slot_mapping), self._to_dev(inp.context_lens),
                         self._to_dev(inp.block_tables))
             return self._to_dev(inp.input_ids), self._to_dev(inp.positions)
-        ids, pos = self._dev_i64[0, :b], self._dev_i64[1, :b]
-        ids.copy_(inp.input_ids, non_blocking=True)
-        pos.copy_(inp.positions, non_blocking=True)
-        slots, ctx = self._dev_slots[:b], self._dev_ctx[:b]
-        slots.copy_(inp.slot_mapping, non_blocking=True)
-        ctx.copy_(inp.context_lens, non_blocking=True)
-        w = inp.block_tables.shape[1]
-        if w and w <= self._dev_tables.shape[1]:
-            tables = self._dev_tables[:b, :w]  # row-strided view, like the reference
-            tables.copy_(inp.block_tables, non_blocking=True)
-        else:
-            tables = self._to_dev(inp.block_tables)
-        set_context(False, 0, 0, None, None, slots, ctx, tables)
-        return ids, pos
+        self._pack_dev.copy_(self.builder.decode_pack, non_blocking=True)
+        tables = self._ship_tables(inp)
+        set_context(False, 0, 0, None, None, self._dev_slots[:b], self._dev_ctx[:b], tables)
+        return self._dev_ids[:b], self._dev_pos[:b]
 
-    def _ship_sampling(self, sequences, b_pad: int | None = None):
+    def _ship_tables(self, inp: BatchInputs):
+        b, w = inp.num_seqs, inp.block_tables.shape[1]
+        if w == 0:
+            return torch.empty((b, 0), dtype=torch.int32, device=self.device)
+        view = self._dev_tables[:b, :w]  # row-strided view, like the reference
+        if inp.tables_dirty:
+            view.copy_(inp.block_tables, non_blocking=True)
+        return view
+
+    def _ship_sampling(self, sequences, b_pad: int | None = None, unchanged: bool = False):
         b = len(sequences)
+        n_rows = b if b_pad is None else b_pad
+        d = self._dev_samp_f32
+        if unchanged and self._samp_rows == n_rows:  # same batch as the previous decode step
+            return d[0, :n_rows], self._dev_samp_i64[:n_rows], d[1, :n_rows], d[2, :n_rows]
+        self._samp_rows = n_rows if b_pad is not None else -1
         f, k = self._samp_f32.numpy(), self._samp_i64.numpy()
         f[0, :b] = [s.temperature for s in sequences]
         f[1, :b] = [s.top_p for s in sequences]
@@ -281,20 +291,19 @@ class InferenceExecutor:
         vocab = self.config.hf_config.vocab_size
         dev = self.device
         gv = self.graph_vars = {
-            "input_ids": torch.zeros(max_bs, dtype=torch.int64, device=dev),
-            "positions": torch.zeros(max_bs, dtype=torch.int64, device=dev),
-            "slot_mapping": torch.full((max_bs,), -1, dtype=torch.int32, device=dev),
-            "context_lens": torch.zeros(max_bs, dtype=torch.int32, device=dev),
-            "block_tables": torch.full((max_bs, self.max_blocks_per_seq), -1, dtype=torch.int32, device=dev),
+            "input_ids": self._dev_ids[:max_bs], "positions": self._dev_pos[:max_bs],
+            "slot_mapping": self._dev_slots[:max_bs], "context_lens": self._dev_ctx[:max_bs],
+            "block_tables": self._dev_tables[:max_bs],
             "logits": torch.zeros((max_bs, vocab), dtype=self.dtype, device=dev),
             "tokens": torch.zeros(max_bs, dtype=torch.int64, device=dev),
-            "rng_offset": torch.zeros(1, dtype=torch.int64, device=dev),
+            "rng_offset": self._dev_rng[:1],
         }
         # the split-KV workspace must exist before capture (no allocation inside a graph)
         hf = self.config.hf_config
         heads = hf.num_attention_heads // get_tensor_parallel_world_size()
-        hip_ops.workspace(hip_ops.paged_decode_workspace_bytes(max_bs, heads, self.num_kv_heads, self.head_dim,
-                                                               self.block_size, self.max_blocks_per_seq), dev)
+        hip_ops.workspace(max(hip_ops.paged_decode_workspace_bytes(bs, heads, self.num_kv_heads, self.head_dim,
+                                                                   self.block_size, self.max_blocks_per_seq)
+                              for bs in self.graph_bs), dev)
         self.sampler.offset_dev = gv["rng_offset"]
         try:
             for bs in reversed(self.graph_bs):
@@ -344,22 +353,18 @@ class InferenceExecutor:
         reset_context()
 
     def _replay_graph(self, bs: int, inp: BatchInputs, sequences):
-        gv = self.graph_vars
+        """One pinned->device copy of the decode pack (+ block tables / sampling parameters only when they
+        changed), then the captured graph: model, LM head and sampler."""
         b = inp.num_seqs
-        gv["input_ids"][:b].copy_(inp.input_ids, non_blocking=True)
-        gv["positions"][:b].copy_(inp.positions, non_blocking=True)
-        if bs > b:  # padded rows: no store (-1 slot), empty context
-            gv["slot_mapping"][b:bs].fill_(-1)
-            gv["context_lens"][b:bs].zero_()
-        gv["slot_mapping"][:b].copy_(inp.slot_mapping, non_blocking=True)
-        gv["context_lens"][:b].copy_(inp.context_lens, non_blocking=True)
-        w = inp.block_tables.shape[1]
-        if w:
-            gv["block_tables"][:b, :w].copy_(inp.block_tables, non_blocking=True)
-        self._ship_sampling(sequences, b_pad=bs)
         self.sampler.calls += 1
-        gv["rng_offset"].fill_(self.sampler.calls)
+        self.builder.p_rng[0] = self.sampler.calls          # Philox offset of this step, inside the pack
+        self._pack_dev.copy_(self.builder.decode_pack, non_blocking=True)
+        w = inp.block_tables.shape[1]
+        if w and inp.tables_dirty:
+            self._dev_tables[:b, :w].copy_(inp.block_tables, non_blocking=True)
+        self._ship_sampling(sequences, b_pad=bs, unchanged=not inp.batch_changed)
         self.graphs[bs].replay()
+        gv = self.graph_vars
         return gv["logits"][:b], gv["tokens"][:b].tolist()
 
     def cleanup(self) -> None:

@@ -36,6 +36,10 @@ class BatchInputs:
     context_lens: torch.Tensor | None = None
     block_tables: torch.Tensor | None = None
     num_seqs: int = 0
+    # decode fast-path hints for the executor (values above are always complete and correct)
+    packed: bool = False          # ids/positions/slots/context_lens are views of InputBuilder.decode_pack
+    tables_dirty: bool = True     # block-table staging changed since the previous decode batch
+    batch_changed: bool = True    # different sequences (or order) than the previous decode batch
 
 
 class InputBuilder:
@@ -55,12 +59,32 @@ class InputBuilder:
         self._np_slots = self._slots.numpy()
         self._np_seq32 = self._seq32.numpy()
         self._np_tables = self._tables.numpy()
+        # decode pack: ONE pinned buffer -> one H2D copy per step.
+        # layout (bytes): ids i64[ms] | positions i64[ms] | slots i32[ms] | context_lens i32[ms] | rng i64[2]
+        ms = max_num_seqs
+        self.pack_layout = {"ids": (0, ms * 8), "pos": (ms * 8, ms * 8), "slots": (ms * 16, ms * 4),
+                            "ctx": (ms * 20, ms * 4), "rng": (ms * 24, 16)}
+        self.pack_nbytes = ms * 24 + 16
+        self.decode_pack = torch.zeros(self.pack_nbytes, dtype=torch.uint8, pin_memory=self.pin)
+        self._p_ids = self.pack_view(self.decode_pack, "ids")
+        self._p_pos = self.pack_view(self.decode_pack, "pos")
+        self._p_slots = self.pack_view(self.decode_pack, "slots")
+        self._p_ctx = self.pack_view(self.decode_pack, "ctx")
+        self.p_rng = self.pack_view(self.decode_pack, "rng")
+        self._last_batch: list | None = None   # decode batch whose block tables are in the staging buffer
+        self._last_table_lens: list[int] = []
+        self._last_width = -1
+
+    def pack_view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
+        off, n = self.pack_layout[name]
+        return buf[off:off + n].view(torch.int32 if name in ("slots", "ctx") else torch.int64)
 
     def _alloc(self, shape, dtype) -> torch.Tensor:
         return torch.zeros(shape, dtype=dtype, pin_memory=self.pin)
 
     # ------------------------------------------------------------------ prefill (a1)
     def prefill(self, sequences: list[Sequence]) -> BatchInputs:
+        self._last_batch = None  # the table staging buffer is about to be reused
         bs = self.block_size
         ids: list[int] = []
         pos: list[np.ndarray] = []
@@ -101,22 +125,54 @@ class InputBuilder:
         return BatchInputs(True, out_ids, out_pos, max_q, max_k, cq, ck, slot_t, None, tables, n)
 
     # ------------------------------------------------------------------ decode (a2)
-    def decode(self, sequences: list[Sequence]) -> BatchInputs:
+    def decode(self, sequences: list[Sequence], pad_to: int | None = None) -> BatchInputs:
+        """``pad_to``: graph bucket size; rows b..pad_to of the pack get slot -1 / context 0 (no KV
+        store, empty attention) like the reference's replay padding (inference_executor.py:758-764)."""
         b, bs = len(sequences), self.block_size
-        ids = self._fit_i64(0, b)
-        pos = self._fit_i64(1, b)
-        slot_t = self._fit_slots(b)
-        ctx = self._fit_seq32(2, b)
+        packed = b <= self.max_num_seqs
+        if packed:
+            ids, pos, slot_t, ctx = self._p_ids[:b], self._p_pos[:b], self._p_slots[:b], self._p_ctx[:b]
+        else:
+            ids, pos = self._fit_i64(0, b), self._fit_i64(1, b)
+            slot_t, ctx = self._fit_slots(b), self._fit_seq32(2, b)
         lens = np.fromiter((s.num_tokens for s in sequences), dtype=np.int64, count=b)
         ids.numpy()[:] = np.fromiter((s.last_token for s in sequences), dtype=np.int64, count=b)
         pos.numpy()[:] = lens - 1
         ctx.numpy()[:] = lens
-        # slot of the token being written: last block, last occupied offset; 0 without a table (warm-up)
-        slot_t.numpy()[:] = np.fromiter(
-            ((s.block_table[-1] * bs + s.last_block_num_tokens - 1) if s.block_table else 0
-             for s in sequences), dtype=np.int32, count=b)
-        tables = self._tables_for(sequences, decode=True)
-        return BatchInputs(False, ids, pos, 0, 0, None, None, slot_t, ctx, tables, b)
+        # slot of the token being written = last block * bs + (len-1) % bs  (== last_block_num_tokens - 1);
+        # 0 without a table (warm-up)
+        last_blk = np.fromiter((s.block_table[-1] if s.block_table else -1 for s in sequences),
+                               dtype=np.int64, count=b)
+        slot_t.numpy()[:] = np.where(last_blk >= 0, last_blk * bs + (lens - 1) % bs, 0)
+        if packed and pad_to is not None and pad_to > b:
+            self._p_slots.numpy()[b:pad_to] = -1
+            self._p_ctx.numpy()[b:pad_to] = 0
+        last = self._last_batch
+        same = (packed and last is not None and len(last) == b
+                and all(x is y for x, y in zip(sequences, last)))
+        tables, dirty = self._tables_decode(sequences, same)
+        self._last_batch = list(sequences) if packed else None
+        return BatchInputs(False, ids, pos, 0, 0, None, None, slot_t, ctx, tables, b,
+                           packed=packed, tables_dirty=dirty, batch_changed=not same)
+
+    def _tables_decode(self, sequences: list[Sequence], same: bool):
+        """Block tables of a decode batch; when the batch is the previous one, only rows whose table
+        grew are rewritten (a block is appended once every block_size steps)."""
+        lens = [len(s.block_table) for s in sequences]
+        width = max(lens) if lens else 0
+        if (not same or width != self._last_width or width == 0
+                or len(sequences) > self.max_num_seqs or width > self.max_blocks_per_seq):
+            out = self._tables_for(sequences, decode=True)
+            self._last_table_lens, self._last_width = lens, width
+            return out, True
+        dirty = False
+        view = self._np_tables
+        for i, (n, old) in enumerate(zip(lens, self._last_table_lens)):
+            if n != old:
+                view[i, :n] = sequences[i].block_table
+                dirty = True
+        self._last_table_lens = lens
+        return self._tables[:len(sequences), :width], dirty
 
     # ------------------------------------------------------------------ block tables
     def _tables_for(self, sequences: list[Sequence], decode: bool) -> torch.Tensor:

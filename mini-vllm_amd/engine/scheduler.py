@@ -75,6 +75,9 @@ class Scheduler:
         return not (bm.needs_block_now(seq) and bm.get_num_free_blocks() == 0)
 
     def _schedule_decode(self) -> list[Sequence]:
+        fast = self._schedule_decode_fast()
+        if fast is not None:
+            return fast
         batch: list[Sequence] = []
         while self.running and len(batch) < self.max_num_seqs:
             seq = self.running.popleft()
@@ -89,6 +92,28 @@ class Scheduler:
                 batch.append(seq)
         if batch:
             self.running.extendleft(reversed(batch))
+        return batch
+
+    def _schedule_decode_fast(self) -> list[Sequence] | None:
+        """Steady-state decode without the per-sequence deque shuffle.  When every running sequence
+        fits the batch and the free pool covers every block that can be asked for this step, the
+        reference loop degenerates to "may_append each sequence in order" with the queue order
+        unchanged — same batch, same block ids, same digests (checked against the reference traces)."""
+        running = self.running
+        if not running or len(running) > self.max_num_seqs:
+            return None
+        bm = self.block_manager
+        bs = bm.block_size
+        pos = [s.num_tokens % bs for s in running]
+        takes = pos.count(1)                      # may_append takes a block at len % bs == 1
+        reserve = 1 if 0 in pos else 0            # can_append wants a free block at len % bs == 0
+        if bm.get_num_free_blocks() < takes + reserve:
+            return None                           # preemption possible: take the general path
+        batch = list(running)
+        if takes or reserve:
+            for s, p in zip(batch, pos):
+                if p <= 1:
+                    bm.may_append(s)              # p == 1: new block; p == 0: publish the digest
         return batch
 
     def preempt(self, sequence: Sequence) -> None:

@@ -21,21 +21,19 @@ with tempfile.TemporaryDirectory() as d:
         t0 = time.perf_counter()
         seqs, is_prefill = eng.scheduler.schedule()
         t1 = time.perf_counter()
-        inp = ex.builder.decode(seqs)
-        t2 = time.perf_counter()
         bs = ex._graph_bucket(len(seqs))
-        gv = ex.graph_vars
+        inp = ex.builder.decode(seqs, pad_to=bs)
+        t2 = time.perf_counter()
         b = inp.num_seqs
-        gv["input_ids"][:b].copy_(inp.input_ids, non_blocking=True)
-        gv["positions"][:b].copy_(inp.positions, non_blocking=True)
-        gv["slot_mapping"][:b].copy_(inp.slot_mapping, non_blocking=True)
-        gv["context_lens"][:b].copy_(inp.context_lens, non_blocking=True)
-        w = inp.block_tables.shape[1]
-        gv["block_tables"][:b, :w].copy_(inp.block_tables, non_blocking=True)
-        ex._ship_sampling(seqs, b_pad=bs)
         ex.sampler.calls += 1
-        gv["rng_offset"].fill_(ex.sampler.calls)
+        ex.builder.p_rng[0] = ex.sampler.calls
+        ex._pack_dev.copy_(ex.builder.decode_pack, non_blocking=True)
+        w = inp.block_tables.shape[1]
+        if w and inp.tables_dirty:
+            ex._dev_tables[:b, :w].copy_(inp.block_tables, non_blocking=True)
+        ex._ship_sampling(seqs, b_pad=bs, unchanged=not inp.batch_changed)
         ex.graphs[bs].replay()
+        gv = ex.graph_vars
         t3 = time.perf_counter()
         toks = gv["tokens"][:b].tolist()
         t4 = time.perf_counter()
