@@ -238,7 +238,7 @@ def main():
         engine.exit()
     if rank != 0:
         return
-    cpu = None if args.no_cpu_baseline else cpu_baseline(args)
+    cpu = None if (args.no_cpu_baseline or args.gpus != 1) else cpu_baseline(args)  # rank 0, N=1 only
     value = args.batch * args.steps / elapsed
     line = {
         "metric": "decode tokens/s", "value": round(value, 1), "unit": "tokens/s", "n_gpus": args.gpus,

@@ -34,7 +34,10 @@ struct SampleParams {
   int vocab;
 };
 
+constexpr int kWin = 2048;  // window histogram: the 2048 distinct 16-bit values just below the row maximum
+
 struct Shared {
+  unsigned wcnt[kWin];
   float fhist[256];
   unsigned ihist[256];
   float fred[kWaves];
@@ -161,20 +164,30 @@ __device__ __forceinline__ void row_foreach(const typename elem<Tag>::T *row, in
   int scalar_from = 0;
   if (vec_ok) {
     const int nvec = vocab / VEC;
-    for (int c0 = 0; c0 < nvec; c0 += kThreads) {
-      const int c = c0 + threadIdx.x;
-      const bool ok = c < nvec;
-      u32x4 raw = {0u, 0u, 0u, 0u};
-      if (ok) raw = *reinterpret_cast<const u32x4 *>(row + (int64_t)c * VEC);
-      if constexpr (VEC == 8) {
+    constexpr int U = 4;  // loads in flight per thread: a pass is L2/MALL-latency bound otherwise
+    for (int c0 = 0; c0 < nvec; c0 += kThreads * U) {
+      u32x4 raw[U];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f(c * VEC + 2 * j, (T)(raw[j] & 0xffffu), ok);
-          f(c * VEC + 2 * j + 1, (T)(raw[j] >> 16), ok);
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * kThreads + threadIdx.x;
+        raw[u] = u32x4{0u, 0u, 0u, 0u};
+        if (c < nvec) raw[u] = *reinterpret_cast<const u32x4 *>(row + (int64_t)c * VEC);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * kThreads + threadIdx.x;
+        const bool ok = c < nvec;
+        if (c0 + u * kThreads >= nvec) break;  // block-uniform: nobody has work in this sub-batch
+        if constexpr (VEC == 8) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f(c * VEC + 2 * j, (T)(raw[u][j] & 0xffffu), ok);
+            f(c * VEC + 2 * j + 1, (T)(raw[u][j] >> 16), ok);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f(c * VEC + j, u2f(raw[u][j]), ok);
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) f(c * VEC + j, u2f(raw[j]), ok);
       }
     }
     scalar_from = nvec * VEC;
@@ -262,11 +275,115 @@ __global__ void __launch_bounds__(kThreads) sample_kernel(SampleParams p) {
   // ---- top-k: k-th largest key, and how many of its ties to keep ----------------------
   const int64_t k_raw = p.top_ks ? p.top_ks[rowi] : -1;
   const bool topk_on = !degenerate && k_raw > 0 && k_raw < (int64_t)V;
+  const float top_p = p.top_ps ? p.top_ps[rowi] : 1.0f;
+  const bool topp_on = !degenerate && top_p < 1.0f;
   uint32_t key_k = 0;        // keep key > key_k, plus `need_ties` elements with key == key_k
   unsigned need_ties = 0;
   bool ties_partial = false; // true when only some of the ties survive
   unsigned tie_before = 0;   // this thread's first tie rank (thread-major order)
-  if (topk_on) {
+  uint32_t key_p = 0;        // keep key >= key_p
+  bool topk_done = false, topp_done = false;
+
+  // ---- 16-bit logits: ONE histogram pass resolves both thresholds.  Every bin of the window is
+  //      exactly one representable value (bin = key(max) - key), so there is no second radix level;
+  //      values below the window only feed a count and a mass.  If a threshold falls below the
+  //      window (flat distributions, huge k) the generic radix select further down takes over.
+  if constexpr (KBITS == 16) {
+    if (topk_on || topp_on) {
+      const uint32_t kmax = make_key<Tag>(elem<Tag>::st(xmax));
+      for (int i = threadIdx.x; i < kWin; i += kThreads) sh.wcnt[i] = 0u;
+      __syncthreads();
+      // only COUNTS are accumulated: all members of a bin are the same value, so its mass is
+      // count * weight(value).  Values below the window need their mass only when top-k is off.
+      unsigned under_c = 0;
+      float under_m = 0.f;
+      row_foreach<Tag>(row, V, vec_ok, [&](int i, T raw, bool ok) {
+        const uint32_t bin = kmax - make_key<Tag>(raw);
+        if (ok) {
+          if (bin < (uint32_t)kWin) {
+            atomicAdd(&sh.wcnt[bin], 1u);
+          } else {
+            ++under_c;
+            if (!topk_on) under_m += weight(elem<Tag>::ld(raw));
+          }
+        }
+      });
+      __syncthreads();
+      auto bin_weight = [&](uint32_t bin) -> float {  // weight of the value that owns `bin`
+        const uint32_t key = kmax - bin;              // invert make_key: sortable key -> raw bits
+        const uint32_t rawbits = (key & 0x8000u) ? (key & 0x7fffu) : (~key & 0xffffu);
+        return weight(elem<Tag>::ld((T)rawbits));
+      };
+      const unsigned c0 = sh.wcnt[2 * threadIdx.x], c1 = sh.wcnt[2 * threadIdx.x + 1];
+      const float m0 = c0 ? (float)c0 * bin_weight(2 * threadIdx.x) : 0.f;
+      const float m1 = c1 ? (float)c1 * bin_weight(2 * threadIdx.x + 1) : 0.f;
+      unsigned win_c;
+      float win_m;
+      const unsigned pc = block_exscan_u(c0 + c1, win_c, sh);   // elements in bins before mine
+      const float pm = block_exscan_f(m0 + m1, win_m, sh);      // their mass
+      const float under_mass = block_sum_f(under_m, sh);
+      unsigned under_cnt;
+      (void)block_exscan_u(under_c, under_cnt, sh);
+      __syncthreads();
+      if (threadIdx.x == 0) { sh.bcast_u[0] = 0xffffffffu; sh.bcast_u[3] = 0u; }
+      __syncthreads();
+      int limit = kWin - 1;       // last bin that still has top-k members
+      float z1 = win_m + under_mass;
+      bool ok_fast = true;
+      if (topk_on) {
+        if (win_c >= (unsigned)k_raw) {
+          const unsigned kk = (unsigned)k_raw;
+          if (pc < kk && kk <= pc + c0 + c1) {  // exactly one thread
+            const bool second = pc + c0 < kk;
+            const unsigned above = second ? pc + c0 : pc;
+            const unsigned bc = second ? c1 : c0;
+            const float bm = second ? m1 : m0;
+            const unsigned need = kk - above;
+            sh.bcast_u[0] = 2 * threadIdx.x + (second ? 1 : 0);
+            sh.bcast_u[1] = need;
+            sh.bcast_u[2] = bc;
+            sh.bcast_f[1] = (second ? pm + m0 : pm) + (float)need * (bm / (float)bc);  // mass of the top-k set
+          }
+          __syncthreads();
+          const unsigned bk = sh.bcast_u[0];
+          key_k = kmax - bk;
+          need_ties = sh.bcast_u[1];
+          ties_partial = need_ties < sh.bcast_u[2];
+          z1 = sh.bcast_f[1];
+          limit = (int)bk;
+          topk_done = true;
+        } else {
+          ok_fast = false;  // the k-th value lies below the window
+        }
+      }
+      if (ok_fast && topp_on) {
+        // largest bin index i <= limit whose strictly-larger mass E_i fits the budget (E_0 = 0 always does)
+        const float budget = top_p * z1;
+        unsigned cand = 0;
+        const int b0 = 2 * threadIdx.x, b1 = b0 + 1;
+        if (b0 <= limit && pm <= budget) cand = (unsigned)b0 + 1u;
+        if (b1 <= limit && pm + m0 <= budget) cand = (unsigned)b1 + 1u;
+        if (cand) atomicMax(&sh.bcast_u[3], cand);
+        __syncthreads();
+        const unsigned bp = sh.bcast_u[3] - 1u;  // >= 0: bin 0 always qualifies
+        // without top-k, "the whole window fits" means the nucleus edge is below the window
+        if (!topk_on && under_cnt > 0 && bp == (unsigned)(kWin - 1) && win_m <= budget) {
+          ok_fast = false;
+        } else {
+          key_p = kmax - bp;
+          topp_done = true;
+        }
+      }
+      if (ties_partial && topk_done) {
+        unsigned mine_t = 0;
+        row_foreach<Tag>(row, V, vec_ok, [&](int i, T raw, bool ok) { mine_t += ok && make_key<Tag>(raw) == key_k; });
+        unsigned tot;
+        tie_before = block_exscan_u(mine_t, tot, sh);
+      }
+    }
+  }
+
+  if (topk_on && !topk_done) {
     uint32_t prefix = 0;
     unsigned above = 0;      // elements with a strictly larger prefix
     unsigned bin_count = 0;
@@ -318,10 +435,7 @@ __global__ void __launch_bounds__(kThreads) sample_kernel(SampleParams p) {
   };
 
   // ---- top-p: smallest key v with mass(key > v) <= p * Z1 -----------------------------
-  const float top_p = p.top_ps ? p.top_ps[rowi] : 1.0f;
-  const bool topp_on = !degenerate && top_p < 1.0f;
-  uint32_t key_p = 0;  // keep key >= key_p
-  if (topp_on) {
+  if (topp_on && !topp_done) {
     float z = 0.f;
     tie_seen = 0;
     row_foreach<Tag>(row, V, vec_ok, [&](int i, T raw, bool ok) {
@@ -395,21 +509,100 @@ __global__ void __launch_bounds__(kThreads) sample_kernel(SampleParams p) {
   if (owner) atomicMax(&sh.bcast_u[3], (unsigned)threadIdx.x + 1u);
   __syncthreads();
   const unsigned who = sh.bcast_u[3] ? sh.bcast_u[3] - 1u : 0u;
-  if (threadIdx.x == who) {
-    float run = before;
+  // The owner's elements are re-examined by ITS WHOLE WAVE: lane L takes the owner's L-th vector
+  // (or L-th scalar-tail element), so the final search is one vector per lane instead of a serial walk.
+  if ((threadIdx.x >> 6) == (who >> 6)) {
+    constexpr int VEC = elem<Tag>::VEC;
+    const int lane = threadIdx.x & 63;
+    const float before_o = __shfl(before, (int)(who & 63), 64);
+    const unsigned tie_before_o = __shfl((int)tie_before, (int)(who & 63), 64);
+    const int nvec = vec_ok ? V / VEC : 0;
+    const int n_own_vec = nvec > (int)who ? (nvec - (int)who + kThreads - 1) / kThreads : 0;
+    const int tail0 = nvec * VEC;
+    const int n_own_tail = V - tail0 > (int)who ? (V - tail0 - (int)who + kThreads - 1) / kThreads : 0;
     int pick = -1, last_kept = -1;
-    tie_seen = 0;
-    row_foreach<Tag>(row, V, vec_ok, [&](int i, T raw, bool ok) {
-      const float w = weight(elem<Tag>::ld(raw));
-      if (ok && kept(make_key<Tag>(raw), w)) {
-        last_kept = i;
-        run += w;
-        if (pick < 0 && run > target) pick = i;
+    float run_base = before_o;
+    unsigned ties_base = tie_before_o;
+    for (int base = 0; base < n_own_vec + n_own_tail; base += 64) {   // wave-uniform trip count
+      const int slot = base + lane;
+      // this lane's elements: one vector of the owner, or one tail element
+      float w[VEC];
+      uint32_t key[VEC];
+      int idx[VEC];
+      int cnt = 0;
+      if (slot < n_own_vec) {
+        const int c = (int)who + slot * kThreads;
+        const u32x4 raw = *reinterpret_cast<const u32x4 *>(row + (int64_t)c * VEC);
+        cnt = VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          T e;
+          if constexpr (VEC == 8) e = (T)((j & 1) ? (raw[j >> 1] >> 16) : (raw[j >> 1] & 0xffffu));
+          else e = u2f(raw[j]);
+          key[j] = make_key<Tag>(e);
+          w[j] = weight(elem<Tag>::ld(e));
+          idx[j] = c * VEC + j;
+        }
+      } else if (slot < n_own_vec + n_own_tail) {
+        const int i = tail0 + (int)who + (slot - n_own_vec) * kThreads;
+        const T e = row[i];
+        cnt = 1;
+        key[0] = make_key<Tag>(e);
+        w[0] = weight(elem<Tag>::ld(e));
+        idx[0] = i;
       }
-    });
+      // tie ranks continue across lanes in the owner's visiting order
+      unsigned my_ties = 0;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) my_ties += (j < cnt && topk_on && ties_partial && key[j] == key_k);
+      unsigned tie_inc = my_ties;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned y = __shfl_up(tie_inc, off, 64);
+        if (lane >= off) tie_inc += y;
+      }
+      unsigned tie_rank = ties_base + tie_inc - my_ties;
+      float mass = 0.f;
+      bool keepj[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        bool k = j < cnt;
+        if (k && topk_on) {
+          if (key[j] < key_k) k = false;
+          else if (key[j] == key_k && ties_partial) k = (tie_rank++) < need_ties;
+        }
+        if (k && topp_on) k = key[j] >= key_p;
+        if (k && minp_on) k = !(w[j] < min_p);
+        keepj[j] = k;
+        if (k) mass += w[j];
+      }
+      float inc = mass;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float y = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += y;
+      }
+      float run = run_base + inc - mass;   // mass of everything before this lane's elements
+      int lp = -1, lk = -1;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        if (keepj[j]) {
+          lk = idx[j];
+          run += w[j];
+          if (lp < 0 && run > target) lp = idx[j];
+        }
+      // first lane (in visiting order) that crossed the target wins; remember the last kept element
+      const unsigned long long hit = __ballot(lp >= 0);
+      if (pick < 0 && hit) pick = __shfl(lp, __ffsll((long long)hit) - 1, 64);
+      const unsigned long long anyk = __ballot(lk >= 0);
+      if (anyk) last_kept = __shfl(lk, 63 - __clzll((long long)anyk), 64);
+      run_base += __shfl(inc, 63, 64);
+      ties_base += __shfl((int)tie_inc, 63, 64);
+      if (pick >= 0) break;  // wave-uniform
+    }
     if (pick < 0) pick = last_kept >= 0 ? last_kept : best_i;  // rounding at the very end
     if (pick < 0 || pick >= V) pick = 0;
-    p.out_tokens[rowi] = pick;
+    if (threadIdx.x == who) p.out_tokens[rowi] = pick;
   }
 }
 

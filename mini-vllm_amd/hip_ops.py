@@ -123,7 +123,8 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     idx = torch.device(device).index or 0
     buf = _workspace.get(idx)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        # generous first allocation: captured graphs hold this pointer, so it must not move later
+        buf = torch.empty(max(int(nbytes), 32 << 20), dtype=torch.uint8, device=device)
         _workspace[idx] = buf
     return buf
 

@@ -57,6 +57,17 @@ def bench_prefill(n_seqs, seqlen, Hq, Hkv, D=128, dtype=torch.bfloat16):
     print(f"prefill {n_seqs}x{seqlen} H={Hq}/{Hkv}: {t*1e3:8.3f} ms  {flops/t/1e12:7.1f} TFLOP/s  {T/t/1e6:6.2f} Mtok/s")
 
 
+def bench_sampler(B, V, temp, top_k, top_p, min_p=0.0, dtype=torch.bfloat16):
+    logits = (torch.randn(B, V, device=DEV) * 3).to(dtype)
+    t_ = torch.full((B,), temp, device=DEV)
+    k_ = torch.full((B,), top_k, dtype=torch.int64, device=DEV)
+    p_ = torch.full((B,), top_p, device=DEV)
+    m_ = torch.full((B,), min_p, device=DEV)
+    t = timeit(lambda: H.sample(logits, t_, k_, p_, m_, seed=1, offset=2), iters=20)
+    bytes_ = B * V * logits.element_size()
+    print(f"sampler B={B} V={V} T={temp} k={top_k} p={top_p} minp={min_p}: {t*1e6:8.1f} us  ({bytes_/t/1e9:7.1f} GB/s per single pass)")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -67,6 +78,11 @@ if __name__ == "__main__":
     bench_prefill(16, 1024, 28, 4)               # Qwen2-7B config 4
     bench_prefill(4, 4096, 28, 4)
     if not a.quick:
+        bench_sampler(256, 151936, 0.0, -1, 1.0)           # greedy
+        bench_sampler(256, 151936, 1.0, -1, 1.0)           # plain multinomial
+        bench_sampler(256, 151936, 0.6, 40, 0.95)          # the reference's cpu_inference_opt.py preset
+        bench_sampler(256, 151936, 0.8, -1, 0.9, 0.05)     # nucleus over the full vocabulary + min-p
+        bench_sampler(8, 151936, 0.6, 40, 0.95)
         bench_decode(256, 16, 8, 128, 4096, layers=2)
         bench_decode(256, 28, 4, 128, 1024)      # Qwen2-7B
         bench_decode(256, 8, 1, 128, 1024)       # 72B @ TP8
