@@ -182,3 +182,47 @@ def test_engine_generate_greedy_eager_equals_graphs(golden_dir, tmp_path):
         assert len(outs) == 4 and all(len(t) == 12 for t in results[-1])
         engine.exit()
     assert results[0] == results[1]
+
+
+def test_llm_from_checkpoint_dir_with_tokenizer(golden_dir, tmp_path):
+    """The full user path: a model directory with config.json + model.safetensors (HF names) + a
+    tokenizer; ``LLM(Config(dir))`` loads it (load_format="auto"), string prompts are tokenised,
+    EOS comes from the tokenizer, text comes back."""
+    from safetensors.torch import save_file
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+
+    from minivllm_amd import LLM, Config, SamplingParams
+
+    z = _load(golden_dir, "qwen3")
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    (d / "config.json").write_text(bytes(z["config_json"]).decode())
+    weights = {k[2:]: torch.from_numpy(z[k].view(np.int16).copy()).view(torch.bfloat16).contiguous()
+               for k in z.files if k.startswith("w:")}
+    save_file(weights, str(d / "model.safetensors"))
+    vocab = {f"w{i}": i for i in range(318)}
+    vocab.update({"<eos>": 318, "<unk>": 319})
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<eos>", unk_token="<unk>").save_pretrained(str(d))
+
+    cfg = Config(str(d), max_model_len=512, max_num_batched_tokens=1024, max_num_seqs=4, dtype="bfloat16",
+                 num_kvcache_blocks=32)
+    llm = LLM(cfg)
+    assert llm.tokenizer is not None and cfg.eos == 318
+    prompts = ["w3 w4 w5 w6 w7", "w100 w101", "w9 " * 70]
+    outs = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=10), use_tqdm=False)
+    assert len(outs) == 3 and all(isinstance(o["text"], str) for o in outs)
+    assert all(1 <= len(o["token_ids"]) <= 10 for o in outs)
+    # the same prompts as token ids give the same continuation (greedy); the prefix cache now holds them
+    ids = [llm.tokenizer.encode(p) for p in prompts]
+    again = llm.generate(ids, SamplingParams(temperature=0.0, max_tokens=10), use_tqdm=False)
+    assert [o["token_ids"] for o in again] == [o["token_ids"] for o in outs]
+    # sampling path through the engine (reference preset of examples/cpu_inference_opt.py)
+    sampled = llm.generate(prompts, SamplingParams(temperature=0.6, top_p=0.95, top_k=40, max_tokens=8, ignore_eos=True),
+                           use_tqdm=False)
+    assert all(len(o["token_ids"]) == 8 and all(0 <= t < 320 for t in o["token_ids"]) for o in sampled)
+    ex = llm.model_runner.inference_executor
+    assert ex.total_decode_tokens > 0 and ex.total_prefill_tokens > 0 and ex.graphs
+    llm.exit()
