@@ -154,6 +154,17 @@ int mv_sample(const void *logits, int64_t ld, const float *temperatures,
               int64_t *out_tokens, uint8_t *keep_mask, int batch, int vocab,
               void *workspace, size_t ws_bytes, int dtype, void *stream);
 
+/* a2 (device side) — advance the decode inputs of a batch by one step WITHOUT the host:
+ * ids <- tokens just sampled, positions += 1, context_lens += 1 (rows with context 0 are padding and
+ * stay 0), slot_mapping += 1 (rows with slot -1 stay -1), *rng_offset += 1.  Appended to the captured
+ * decode graph so that the NEXT step can be replayed speculatively before the host has read this step's
+ * tokens; the host rewrites all of these whenever the batch changes or a sequence enters a new block.
+ * Replaces, for consecutive steps of an unchanged batch, the per-step refresh of
+ * InferenceExecutor._prepare_decode_input (minivllm/engine/inference_executor.py:551-617). */
+int mv_decode_advance(int64_t *input_ids, const int64_t *tokens, int64_t *positions,
+                      int32_t *slot_mapping, int32_t *context_lens, int64_t *rng_offset,
+                      int batch, void *stream);
+
 /* K9 — SiluAndMul: out[r, c] = silu(x[r, c]) * x[r, cols + c].
  * Replaces SiluAndMul.forward (minivllm/models/layers/activation.py:70-96). */
 int mv_silu_and_mul(const void *x, int64_t x_stride, void *out,

@@ -83,6 +83,13 @@ class InferenceExecutor:
         self._dev_rng = b_.pack_view(self._pack_dev, "rng")
         self._dev_tables = torch.full((ms, self.max_blocks_per_seq), -1, dtype=torch.int32, device=self.device)
         self._samp_rows = -1  # rows of the device sampling planes that are current (-1: stale)
+        # speculative next-step replay (see _replay_graph): set by the engine when nothing is waiting
+        self.speculate_next = False
+        self._spec = None            # (batch, bucket, expected lens, event, host token slot) of the step in flight
+        self._tok_host = [torch.zeros(ms, dtype=torch.int64, pin_memory=self.device.type == "cuda") for _ in range(3)]
+        self._tok_events = [torch.cuda.Event() for _ in range(3)] if self.device.type == "cuda" else []
+        self._tok_slot = 0
+        self.spec_hits = self.spec_misses = 0
         # sampling parameters: one pinned plane, one device plane  [temps | top_ps | min_ps] f32, top_ks i64
         pin = self.device.type == "cuda"
         self._samp_f32 = torch.zeros((3, ms), dtype=torch.float32, pin_memory=pin)
@@ -179,6 +186,7 @@ class InferenceExecutor:
             return torch.empty(0, device=self.device), []
         try:
             if prefill:
+                self._spec = None  # a speculative decode step in flight (if any) is simply ignored
                 inp = self.builder.prefill(sequences)
                 ids, pos = self._ship_prefill(inp, sequences)
                 logits = self.model.compute_logits(self.model(ids, pos))
@@ -335,6 +343,9 @@ class InferenceExecutor:
         toks = hip_ops.sample(gv["logits"][:bs], d[0, :bs], self._dev_samp_i64[:bs], d[1, :bs], d[2, :bs],
                               seed=self.sampler.seed, offset=0, offset_dev=gv["rng_offset"])
         gv["tokens"][:bs].copy_(toks)
+        # last node: advance the device-side decode inputs so that the NEXT step can be replayed as is
+        hip_ops.decode_advance(gv["input_ids"][:bs], gv["tokens"][:bs], gv["positions"][:bs],
+                               gv["slot_mapping"][:bs], gv["context_lens"][:bs], gv["rng_offset"])
 
     @torch.inference_mode()
     def _capture_one(self, bs: int) -> None:
@@ -354,18 +365,63 @@ class InferenceExecutor:
 
     def _replay_graph(self, bs: int, inp: BatchInputs, sequences):
         """One pinned->device copy of the decode pack (+ block tables / sampling parameters only when they
-        changed), then the captured graph: model, LM head and sampler."""
+        changed), then the captured graph: model, LM head, sampler, input advance.
+
+        Speculative next step: the graph ends by advancing its own inputs on the device (ids <- sampled
+        tokens, positions/context/slots + 1), so when the engine says nothing is waiting and no sequence
+        of the batch is about to finish or to enter a new block, the NEXT step's graph is enqueued right
+        behind this one, before the host has even read this step's tokens.  The host's scheduling,
+        input building and bookkeeping then overlap GPU work instead of leaving it idle between steps.
+        On the next call the speculation is validated (same sequences, same order, every length + 1,
+        block tables untouched); a miss (EOS, preemption, new request) just overwrites the device state
+        from the host as usual — the speculative step only re-wrote K/V rows that the real step rewrites
+        with identical values or that belong to finished sequences."""
         b = inp.num_seqs
-        self.sampler.calls += 1
-        self.builder.p_rng[0] = self.sampler.calls          # Philox offset of this step, inside the pack
-        self._pack_dev.copy_(self.builder.decode_pack, non_blocking=True)
-        w = inp.block_tables.shape[1]
-        if w and inp.tables_dirty:
-            self._dev_tables[:b, :w].copy_(inp.block_tables, non_blocking=True)
-        self._ship_sampling(sequences, b_pad=bs, unchanged=not inp.batch_changed)
-        self.graphs[bs].replay()
         gv = self.graph_vars
-        return gv["logits"][:b], gv["tokens"][:b].tolist()
+        spec, self._spec = self._spec, None
+        hit = False
+        if spec is not None:
+            batch, sbs, lens, slot = spec
+            hit = (sbs == bs and len(batch) == b and not inp.tables_dirty and not inp.batch_changed
+                   and all(x is y for x, y in zip(batch, sequences))
+                   and all(s.num_tokens == n for s, n in zip(sequences, lens)))
+            self.spec_hits += hit
+            self.spec_misses += not hit
+        if hit:
+            slot_now = slot  # this step is already executing (or done): its tokens land in that slot
+        else:
+            self.sampler.calls += 1
+            self.builder.p_rng[0] = self.sampler.calls      # Philox offset of this step, inside the pack
+            self._pack_dev.copy_(self.builder.decode_pack, non_blocking=True)
+            w = inp.block_tables.shape[1]
+            if w and inp.tables_dirty:
+                self._dev_tables[:b, :w].copy_(inp.block_tables, non_blocking=True)
+            self._ship_sampling(sequences, b_pad=bs, unchanged=not inp.batch_changed)
+            self.graphs[bs].replay()
+            slot_now = self._stash_tokens(b)
+        if self.speculate_next and self._can_speculate(sequences):
+            self.sampler.calls += 1                          # the graph advanced the device-side offset itself
+            self.graphs[bs].replay()
+            self._spec = (list(sequences), bs, [s.num_tokens + 1 for s in sequences], self._stash_tokens(b))
+        self._tok_events[slot_now].synchronize()
+        return gv["logits"][:b], self._tok_host[slot_now][:b].tolist()
+
+    def _stash_tokens(self, b: int) -> int:
+        """Async D2H of the step that was just enqueued into a pinned ring slot + an event to wait on."""
+        slot = self._tok_slot
+        self._tok_slot = (slot + 1) % len(self._tok_host)
+        self._tok_host[slot][:b].copy_(self.graph_vars["tokens"][:b], non_blocking=True)
+        self._tok_events[slot].record()
+        return slot
+
+    def _can_speculate(self, sequences) -> bool:
+        bs = self.block_size
+        for s in sequences:
+            # after this step the sequence has num_tokens + 1 tokens; the step after that needs a new block
+            # iff num_tokens % bs == 0, and there is no such step if this token exhausts max_tokens
+            if s.num_tokens % bs == 0 or s.num_completion_tokens + 1 >= s.max_tokens:
+                return False
+        return True
 
     def cleanup(self) -> None:
         self.graphs.clear()

@@ -114,6 +114,9 @@ class LLMEngine:
     def step(self):
         """-> ([(seq_id, completion_token_ids) for finished], +prefill tokens | -decode seqs)."""
         sequences, is_prefill = self.scheduler.schedule()
+        ex = getattr(self.model_runner, "inference_executor", None)
+        if ex is not None:  # hint: with nothing waiting, the next step is a decode of (at most) this batch
+            ex.speculate_next = not self.scheduler.waiting
         token_ids = self.model_runner.call("run", sequences, is_prefill)
         if token_ids is None:
             raise RuntimeError("ModelRunner returned no tokens on rank 0")

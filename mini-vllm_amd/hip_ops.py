@@ -45,6 +45,7 @@ _SIGNATURES = {
     "mv_sample": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
                           c_uint64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t,
                           c_int, c_void_p]),
+    "mv_decode_advance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mv_silu_and_mul": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -315,3 +316,14 @@ def silu_and_mul(x):
     _check(_lib.mv_silu_and_mul(x2.data_ptr(), x2.stride(0), out.data_ptr(), out.stride(0), x2.shape[0],
                                 cols, _dt(x), _stream()), "mv_silu_and_mul")
     return out.view(*x.shape[:-1], cols)
+
+
+# ---------------------------------------------------------------- a2 (device side)
+def decode_advance(input_ids, tokens, positions, slot_mapping, context_lens, rng_offset) -> None:
+    """In place: ids <- tokens, positions/context/slots += 1 (padding rows untouched), rng += 1."""
+    _need_cuda(input_ids, tokens, positions, slot_mapping, context_lens, rng_offset)
+    assert input_ids.dtype == tokens.dtype == positions.dtype == torch.int64
+    assert slot_mapping.dtype == context_lens.dtype == torch.int32
+    _check(_lib.mv_decode_advance(input_ids.data_ptr(), tokens.data_ptr(), positions.data_ptr(),
+                                  slot_mapping.data_ptr(), context_lens.data_ptr(), _ptr(rng_offset),
+                                  input_ids.shape[0], _stream()), "mv_decode_advance")

@@ -226,3 +226,38 @@ def test_llm_from_checkpoint_dir_with_tokenizer(golden_dir, tmp_path):
     ex = llm.model_runner.inference_executor
     assert ex.total_decode_tokens > 0 and ex.total_prefill_tokens > 0 and ex.graphs
     llm.exit()
+
+
+def test_speculative_replay_matches_eager_across_finishes(golden_dir, tmp_path):
+    """Requests finishing at different steps (max_tokens 3..40, one EOS hit), a block boundary inside the
+    run and a late-arriving request: the graph path with speculative next-step replay must produce
+    exactly the eager tokens, and must actually have speculated."""
+    from minivllm_amd import LLM, Config, SamplingParams
+
+    z = _load(golden_dir, "qwen3")
+    d = tmp_path / "m"
+    d.mkdir()
+    (d / "config.json").write_text(bytes(z["config_json"]).decode())
+    weights = {k[2:]: torch.from_numpy(z[k].view(np.int16).copy()).view(torch.bfloat16).float()
+               for k in z.files if k.startswith("w:")}
+    prompts = [list(range(3, 3 + n)) for n in (60, 5, 63, 20, 64)]      # 63/64: block edges while decoding
+    sps = [SamplingParams(temperature=0.0, max_tokens=m, ignore_eos=(i != 1)) for i, m in enumerate((3, 40, 9, 17, 30))]
+    results, stats = [], []
+    for eager in (True, False):
+        cfg = Config(str(d), max_model_len=512, max_num_batched_tokens=1024, max_num_seqs=8, enforce_eager=eager,
+                     dtype="bfloat16", num_kvcache_blocks=32, load_format="dummy", seed=0)
+        engine = LLM(cfg)
+        engine.model_runner.model_manager.model.load_weights(weights)
+        if not results:  # pick an EOS id that request 1 really emits (from a dry greedy run)
+            dry = engine.generate([prompts[1]], SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True), use_tqdm=False)
+            eos = dry[0]["token_ids"][12]
+        engine.scheduler.eos = eos
+        outs = engine.generate(prompts, sps, use_tqdm=False)
+        results.append([o["token_ids"] for o in outs])
+        ex = engine.model_runner.inference_executor
+        stats.append((ex.spec_hits, ex.spec_misses))
+        engine.exit()
+    assert results[0] == results[1]
+    assert len(results[0][1]) <= 13 and results[0][1][-1] == eos          # stopped at the EOS
+    assert [len(t) for i, t in enumerate(results[0]) if i != 1] == [3, 9, 17, 30]
+    assert stats[0] == (0, 0) and stats[1][0] > 5                          # eager never speculates; graphs did
