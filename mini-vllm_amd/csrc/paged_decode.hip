@@ -151,8 +151,10 @@ __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
         row = blk_ok ? (int64_t)blk * p.block_size + (tk - bi * p.block_size) : 0;
       }
       valid[i] = ok;
-      kraw[i] = *reinterpret_cast<const u32x4 *>(kbase + row * row_stride);
-      vraw[i] = *reinterpret_cast<const u32x4 *>(vbase + row * row_stride);
+      // K/V rows are read exactly once per step and 30 GB never fit the 256 MiB Infinity Cache:
+      // non-temporal loads keep them from evicting the weights / activations that do get re-used
+      kraw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(kbase + row * row_stride));
+      vraw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(vbase + row * row_stride));
       if (!ok) vraw[i] = u32x4{0u, 0u, 0u, 0u};  // row 0 of a foreign block may hold anything (0 * NaN)
     }
 

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256, 4) paged_decode_mfma_kernel(DecodeParams 
       const int ch = i16 ^ (((lrow & 3) << 2) | ((lrow >> 2) & 3));
       const T *src = vb + kk * row_elems + 8 * ch;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)(vlds + n * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void *)(vlds + n * 1024), 16, 0, 2 /* nt: whole rows, read once */);
     }
     // ---- K: A operand, lane (key = i16, quad) reads 16 B at d = 32s + 8 quad of key 16kt + i16
     u32x4 kf[2][4];
@@ -135,6 +135,8 @@ __global__ void __launch_bounds__(256, 4) paged_decode_mfma_kernel(DecodeParams 
       const int kk = min(16 * kt + i16, n_valid - 1);  // past the context: re-read a valid key (masked below)
 #pragma unroll
       for (int s = 0; s < 4; ++s)
+        // plain loads: the four 64-B pieces of a 256-B row arrive in four instructions, the cache must
+        // keep each 128-B line until its second half is read (non-temporal K loads measured 8 % slower)
         kf[kt][s] = *reinterpret_cast<const u32x4 *>(kb + kk * row_elems + 32 * s + 8 * quad);
     }
     // (K loads are issued AFTER the V DMA below: vmcnt retires in order, so "K has landed" implies
