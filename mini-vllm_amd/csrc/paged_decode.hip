@@ -249,19 +249,42 @@ __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
   }
 }
 
+// Split-KV combine: one workgroup per (sequence, head), one thread per output dim.  The (m, l) pairs
+// go through LDS once; the partial rows are then summed with independent, unrolled loads (the serial
+// "load, scale, add" chain of a naive loop costs one L2 round trip per split: 10 us at 32 splits).
 template <typename Tag, int D>
-__global__ void paged_decode_reduce_kernel(const float *__restrict__ ws_acc,
-                                           const float *__restrict__ ws_ml,
-                                           typename elem<Tag>::T *__restrict__ out, int nsplit) {
+__global__ void __launch_bounds__(D) paged_decode_reduce_kernel(const float *__restrict__ ws_acc,
+                                                                const float *__restrict__ ws_ml,
+                                                                typename elem<Tag>::T *__restrict__ out,
+                                                                int nsplit) {
+  __shared__ float sm[64], sl[64];  // kMaxSplits
   const int64_t bh = blockIdx.x;
   const int d = threadIdx.x;
+  if (d < nsplit) {
+    sm[d] = ws_ml[(bh * nsplit + d) * 2];
+    sl[d] = ws_ml[(bh * nsplit + d) * 2 + 1];
+  }
+  __syncthreads();
   float M = -1e30f;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ws_ml[(bh * nsplit + s) * 2]);
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, sm[s]);
   float L = 0.f, A = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float f = __builtin_amdgcn_exp2f(ws_ml[(bh * nsplit + s) * 2] - M);
-    L += ws_ml[(bh * nsplit + s) * 2 + 1] * f;
-    A += ws_acc[(bh * nsplit + s) * D + d] * f;
+  const float *row = ws_acc + bh * nsplit * D + d;
+  int s = 0;
+  for (; s + 8 <= nsplit; s += 8) {
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = row[(int64_t)(s + u) * D];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float f = __builtin_amdgcn_exp2f(sm[s + u] - M);
+      L += sl[s + u] * f;
+      A += a[u] * f;
+    }
+  }
+  for (; s < nsplit; ++s) {
+    const float f = __builtin_amdgcn_exp2f(sm[s] - M);
+    L += sl[s] * f;
+    A += row[(int64_t)s * D] * f;
   }
   out[bh * D + d] = elem<Tag>::st(L > 0.f ? A / L : 0.f);
 }
