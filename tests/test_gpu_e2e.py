@@ -261,3 +261,88 @@ def test_speculative_replay_matches_eager_across_finishes(golden_dir, tmp_path):
     assert len(results[0][1]) <= 13 and results[0][1][-1] == eos          # stopped at the EOS
     assert [len(t) for i, t in enumerate(results[0]) if i != 1] == [3, 9, 17, 30]
     assert stats[0] == (0, 0) and stats[1][0] > 5                          # eager never speculates; graphs did
+
+
+def test_config2_qwen3_0p6b_true_dims_vs_cpu_oracle(tmp_path):
+    """BASELINE config 2: Qwen3-0.6B dimensions (28 layers, 16/8 heads, D=128, vocab 151936), bf16,
+    enforce_eager — GPU logits against the CPU oracle (fp32 math on the same bf16 weights), prefill and
+    three decode steps.  Weights are random (no checkpoint offline) but shared bit for bit."""
+    import bench
+    from oracle.model import OracleModel
+
+    from minivllm_amd.config import Config
+    from minivllm_amd.engine.block_manager import BlockManager
+    from minivllm_amd.engine.inference_executor import InferenceExecutor
+    from minivllm_amd.engine.input_builder import InputBuilder
+    from minivllm_amd.engine.sequence import Sequence
+    from minivllm_amd.glue import create_model
+
+    cfg_d = dict(bench.MODELS["qwen3-0.6b"])
+    cfg_d["num_hidden_layers"] = 8          # true width / heads / vocab; 8 of the 28 layers keep the CPU side short
+    (tmp_path / "config.json").write_text(json.dumps(cfg_d))
+    ref = OracleModel.random(cfg_d, dtype=torch.bfloat16, seed=1, num_blocks=8)
+    for k in list(ref.w):                   # sharpen the norms a little so that they matter
+        if k.endswith("norm.weight"):
+            ref.w[k] = (1 + 0.1 * torch.randn(ref.w[k].shape, generator=torch.Generator().manual_seed(len(k)))).bfloat16()
+    cfg = Config(str(tmp_path), num_kvcache_blocks=8, max_model_len=512, max_num_batched_tokens=1024, max_num_seqs=4,
+                 enforce_eager=True, dtype="bfloat16")
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(DEV):
+            model = create_model(cfg.hf_config)
+    finally:
+        torch.set_default_dtype(prev)
+    model.load_weights({k: v.float() for k, v in ref.w.items()})
+    model = model.to(device=DEV, dtype=torch.bfloat16)
+    ex = InferenceExecutor(cfg, model, torch.device(DEV))
+    ex._allocate_kv_cache(); ex._initialize_sampler(); ex._optimize_model()
+    # fp32 oracle on the same (bf16-representable) weights
+    ref32 = OracleModel(cfg_d, {k: v.float() for k, v in ref.w.items()}, torch.float32, num_blocks=8)
+    g = torch.Generator().manual_seed(0)
+    prompts = [torch.randint(0, cfg_d["vocab_size"], (n,), generator=g).tolist() for n in (70, 33)]
+    bm, ib = BlockManager(8, 64), InputBuilder(64, 4, 512, 1024)
+    seqs = [Sequence(p, block_size=64) for p in prompts]
+    for s in seqs:
+        bm.allocate(s)
+
+    def oracle_step(prefill):
+        inp = ib.prefill(seqs) if prefill else ib.decode(seqs)
+        meta = dict(is_prefill=prefill, slot_mapping=inp.slot_mapping, block_tables=inp.block_tables,
+                    cu_q=inp.cum_seqlens_q, cu_k=inp.cum_seqlens_k, context_lens=inp.context_lens)
+        return ref32.forward_logits(inp.input_ids.clone(), inp.positions.clone(), meta).float()
+
+    for step in range(4):
+        want = oracle_step(step == 0)
+        got, toks = ex.execute_batch(seqs, prefill=(step == 0))
+        got = got.float().cpu()
+        scale = want.abs().max().item()
+        err = (got - want).abs().max().item()
+        # bf16 activations through 8 layers against fp32 math: a few bf16 ulps of the logit scale
+        assert err <= 0.03 * scale, f"step {step}: err {err:.4f} scale {scale:.3f}"
+        cos = torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item()
+        assert cos > 0.999, f"step {step}: cosine {cos}"   # the reference's own model-level bar is 0.99
+        nxt = want.argmax(-1).tolist()
+        for s, t in zip(seqs, nxt):
+            s.append_token(int(t))
+            bm.may_append(s)
+
+
+def test_kv_cache_auto_sizing_and_graph_buckets(golden_dir, tmp_path):
+    """a10: with num_kvcache_blocks=-1 the pool is min(memory budget // block bytes, max_num_seqs *
+    ceil(max_model_len / block)) and is written back into the Config (the scheduler sizes itself from it)."""
+    from minivllm_amd.engine.inference_executor import graph_batch_sizes, kv_block_bytes
+
+    z = _load(golden_dir, "qwen3")
+    cfg, model, ex = _build(tmp_path, z, torch.bfloat16)
+    cfg.num_kvcache_blocks = -1
+    ex.kv_cache = None
+    ex._allocate_kv_cache()
+    assert cfg.num_kvcache_blocks == 8 * (512 // 64)               # the cap: memory is not the limit here
+    L, n, bs, hkv, d = ex.kv_cache.shape[1:]
+    assert (L, bs, hkv, d) == (2, 64, 2, 128)
+    assert ex.kv_cache.numel() * 2 == n * kv_block_bytes(2, 64, 2, 128, 2)
+    att = model.model.layers[1].self_attn.attn
+    assert att.k_cache.data_ptr() == ex.kv_cache[0, 1].data_ptr() and att.v_cache.data_ptr() == ex.kv_cache[1, 1].data_ptr()
+    assert graph_batch_sizes(256) == [1, 2, 4, 8, 12] + list(range(16, 257, 16))
+    assert graph_batch_sizes(8) == [1, 2, 4, 8] and graph_batch_sizes(1000)[-1] == 512
