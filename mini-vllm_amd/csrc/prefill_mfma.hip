@@ -60,6 +60,7 @@ template <typename Tag>
 __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
   typedef typename elem<Tag>::T T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // two K|V tile buffers: tile t+1 is written while tile t is being read -> ONE barrier per tile
   char *ldsK = smem;
   char *ldsV = smem + TILE_BYTES;
 
@@ -136,37 +137,56 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
       vreg[i] = *reinterpret_cast<const u32x4 *>(vsrc + (base_row + row) * vstride + hkv * D + ch * 8);
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int buf) {
+    char *dk = smem + buf * 2 * TILE_BYTES, *dv = dk + TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pc = tid + 256 * i;
       const int row = pc >> 4, ch = pc & 15;
-      *reinterpret_cast<u32x4 *>(ldsK + k_off(row, ch)) = kreg[i];
-      *reinterpret_cast<u32x4 *>(ldsV + v_off(row, ch)) = vreg[i];
+      *reinterpret_cast<u32x4 *>(dk + k_off(row, ch)) = kreg[i];
+      *reinterpret_cast<u32x4 *>(dv + v_off(row, ch)) = vreg[i];
     }
   };
 
-  if (n_tiles > 0) fetch(0);
+  // ---- loop-invariant LDS read offsets (the tile-relative part is an instruction immediate)
+  // K, A operand of k-step s: row r (+32 kt), chunk (2s+h) ^ (r & 15)
+  int koff[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) koff[s] = r * ROW_BYTES + (((2 * s + h) ^ (r & 15)) << 4);
+  // V^T, A operand of d-tile dt: rows 4h+q4 (+8) (+32 kt + 16 s2), chunk (4dt + 2g + pp/2) ^ swizzle(row)
+  const int q4 = i16 >> 2, pp = i16 & 3;
+  int voff_lo[NDT], voff_hi[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    const int ch = 4 * dt + 2 * g + (pp >> 1);
+    voff_lo[dt] = v_off(4 * h + q4, ch) + 8 * (pp & 1);
+    voff_hi[dt] = v_off(4 * h + q4 + 8, ch) + 8 * (pp & 1);
+  }
+
+  bool tile_ok = true;
+  if (n_tiles > 0) {
+    fetch(0);
+    tile_ok = tile_ok_next;
+    stage(0);
+  }
+  __syncthreads();
   for (int t = 0; t < n_tiles; ++t) {
-    __syncthreads();  // every wave is done reading the previous tile
-    stage();
-    __syncthreads();
-    const bool tile_ok = tile_ok_next;
-    if (t + 1 < n_tiles) fetch(t + 1);  // in flight during this tile's MFMAs
+    ldsK = smem + (t & 1) * 2 * TILE_BYTES;
+    ldsV = ldsK + TILE_BYTES;
+    const bool have_next = t + 1 < n_tiles;
+    if (have_next) fetch(t + 1);  // global -> registers, in flight during this tile's MFMAs
     const int kv0 = t * BN;
 
     // ---- S^T = K Q^T : two 32-key tiles (raw, unscaled scores; first k-step starts from an inline 0)
     f32x16 sacc[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      const int krow = kt * 32 + r;
       const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      sacc[kt] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(ldsK + k_off(krow, h)), qf[0], zero16);
+      const char *kt_base = ldsK + kt * 32 * ROW_BYTES;  // (row + 32) & 15 == row & 15: same swizzle
+      sacc[kt] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(kt_base + koff[0]), qf[0], zero16);
 #pragma unroll
-      for (int s = 1; s < NS; ++s) {
-        const u32x4 a = *reinterpret_cast<const u32x4 *>(ldsK + k_off(krow, 2 * s + h));
-        sacc[kt] = mfma<Tag>(a, qf[s], sacc[kt]);
-      }
+      for (int s = 1; s < NS; ++s)
+        sacc[kt] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(kt_base + koff[s]), qf[s], sacc[kt]);
     }
 
     // ---- mask (only tiles that touch the diagonal / the ragged end: wave-uniform branch)
@@ -219,26 +239,28 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
         for (int j = 0; j < 4; ++j)
           pf[kt][s2][j] = pack2<Tag>(sacc[kt][8 * s2 + 2 * j], sacc[kt][8 * s2 + 2 * j + 1]);
 
-    // ---- O^T += V^T P^T
-    const int q4 = i16 >> 2, pp = i16 & 3;
+    // ---- O^T += V^T P^T   (rows 32kt + 16s2 + ... keep (row & 3) and ((row >> 2) & 3) of the base row:
+    //      the swizzle term is loop invariant, only the row base moves by a multiple of 16 rows)
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
-      const int ch = 4 * dt + 2 * g + (pp >> 1);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const int rb = kt * 32 + 16 * s2 + 4 * h + q4;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (lds_s16x4 *)(ldsV + v_off(rb, ch) + 8 * (pp & 1)));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (lds_s16x4 *)(ldsV + v_off(rb + 8, ch) + 8 * (pp & 1)));
+          const char *vb_ = ldsV + (kt * 32 + 16 * s2) * ROW_BYTES;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(vb_ + voff_lo[dt]));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(vb_ + voff_hi[dt]));
           // the transposed read already delivers packed 16-bit pairs: reinterpret, do not repack
           const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
           const u32x4 a = {lo2.x, lo2.y, hi2.x, hi2.y};
           oacc[dt] = mfma<Tag>(a, pf[kt][s2], oacc[dt]);
         }
     }
+    // registers -> the OTHER buffer (last read one iteration ago, behind the previous barrier), then the
+    // single barrier of this tile: publishes tile t+1 and retires every wave's reads of tile t
+    if (have_next) stage((t + 1) & 1);
+    tile_ok = tile_ok_next;
+    __syncthreads();
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (r,h) owns d = 32dt + 8c + 4h + {0..3}
@@ -266,7 +288,7 @@ int mv_prefill_mfma_launch(const PrefillParams &p, int dtype, hipStream_t stream
   const int q_blocks = (p.max_seqlen_q + BM - 1) / BM;
   if (q_blocks == 0 || p.n_seqs == 0) return MV_OK;
   dim3 grid(p.n_heads, p.n_seqs, q_blocks), block(256);
-  const size_t lds = 2 * TILE_BYTES;
+  const size_t lds = 4 * TILE_BYTES;  // 2 x (K tile + V tile) = 64 KiB -> two workgroups per CU
   if (dtype == MV_BF16)
     hipLaunchKernelGGL((prefill_mfma_kernel<bf16_tag>), grid, block, lds, stream, p);
   else
