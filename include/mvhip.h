@@ -171,6 +171,26 @@ int mv_silu_and_mul(const void *x, int64_t x_stride, void *out,
                     int64_t out_stride, int rows, int cols, int dtype,
                     void *stream);
 
+/* K10 — decode-sized linear layer: out[m, :] = x[m, :] . W^T (+ bias), 1 <= M <= 64 rows, 16-bit
+ * dtypes, fp32 accumulation, one rounding at the end.  Replaces the F.linear calls of the decode step
+ * (minivllm/models/layers/linear.py:130,163,316; layers/embed_head.py:217) while the batch is small
+ * enough that the projection is a pure HBM stream of W; larger M stays on hipBLASLt.
+ * x [M,K] row stride x_stride; w [N,K] contiguous (torch Linear layout); bias [N] or NULL;
+ * out [M,N] row stride out_stride.  K % 32 == 0, N % 4 == 0; MV_E_SHAPE otherwise (and for fp32 /
+ * M > 64) so that the caller can fall back to the library GEMM. */
+int mv_linear_small_m(const void *x, int64_t x_stride, const void *w,
+                      const void *bias, void *out, int64_t out_stride, int m,
+                      int n, int k, int dtype, void *stream);
+
+/* K10 + K9 — decode-sized gate_up projection with SiluAndMul in its epilogue:
+ * out[m, j] = silu(x[m,:] . Wg[j,:]) * (x[m,:] . Wu[j,:]),  w_gate_up = [Wg ; Wu] of shape [2*n_inter, K]
+ * (the merged layout of MergedColumnParallelLinear, minivllm/models/layers/linear.py:166-231), with the
+ * rounding points of the unfused pair gate_up_proj -> act_fn (minivllm/models/qwen_base.py:232-234):
+ * both GEMM outputs, silu and the product are each rounded to dtype.  Same limits as mv_linear_small_m. */
+int mv_gate_up_silu_small_m(const void *x, int64_t x_stride, const void *w_gate_up,
+                            void *out, int64_t out_stride, int m, int n_inter,
+                            int k, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

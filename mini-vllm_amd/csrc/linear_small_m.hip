@@ -1,0 +1,238 @@
+// K10 — y[M,N] = x[M,K] · W[N,K]ᵀ (+ bias) for the decode-sized M (≤ 64 rows): the weight-streaming
+// form of the reference's F.linear calls (minivllm/models/layers/linear.py:130,163,316,
+// layers/embed_head.py:217) when a decode step carries 1..64 tokens.
+//
+// At these M every projection is a pure HBM stream of W (2·M flop per weight byte ≪ the machine
+// balance), and the library GEMMs are latency-bound on their few output tiles (11–17 µs for 8–50 MB
+// of weights).  Here a workgroup owns RPW·16 weight rows and ALL of K:
+//   * each wave takes a contiguous K slice of those rows and streams it straight from HBM into
+//     the A operand of v_mfma_f32_16x16x32 (lane = (row, 8-element k group): 16 rows × 64 B per
+//     load instruction, every load of the slice in flight before the first wait) — no LDS on the
+//     weight path (guide §5, "GEMV / M ≤ 16" row);
+//   * x (L2-resident, ≤ 0.8 MB) is read in the same fragment shape as the B operand, MT = ⌈M/16⌉
+//     fragments per k step; rows beyond M re-read row M-1 and their output columns are dropped;
+//   * the waves' partial 16×16 tiles are summed through LDS in wave order (deterministic),
+//     bias is added in fp32, one rounding to the output dtype (the GEMM epilogue's rounding point).
+// GATED variant (mv_gate_up_silu_small_m): W = [gate rows | up rows] of the merged gate_up projection; a
+// wave streams RPW gate tiles AND the RPW up tiles of the same output columns, and the epilogue
+// applies SiluAndMul with the rounding points of the unfused pair (GEMM output -> dtype, silu -> dtype,
+// product -> dtype), so the activation never exists as a [M, 2I] tensor and one launch disappears.
+// No workspace, no atomics, no inter-workgroup traffic: hipGraph-capturable as is.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+template <typename Tag>
+__device__ __forceinline__ f32x4 mfma16(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
+  if constexpr (__is_same(Tag, bf16_tag))
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+struct LinearParams {
+  const void *x, *w, *bias;
+  void *out;
+  int64_t x_stride, out_stride;
+  int M, N, K;  // N = output columns (GATED: W has 2N rows, up rows start at row N)
+};
+
+// k steps (32 elements each) whose loads are issued together before the first MFMA
+// (16–20 wave-wide loads in flight per wave)
+__host__ __device__ constexpr int unroll_of(int rpw, int mt) { return rpw + mt <= 2 ? 8 : (rpw + mt <= 5 ? 4 : 2); }
+
+template <typename Tag, int RPW, int MT, bool GATED>
+__global__ void __launch_bounds__(1024) linear_small_m_kernel(LinearParams p) {
+  typedef uint16_t T;
+  extern __shared__ float red[];  // [waves][RPW*MT][64][4]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * (RPW * 16);
+  constexpr int NA = GATED ? 2 * RPW : RPW;  // weight tiles per wave
+  constexpr int kUnroll = unroll_of(NA, MT);
+  const int steps = p.K >> 5;
+  const int s_lo = (int)((int64_t)steps * wave / nwaves), s_hi = (int)((int64_t)steps * (wave + 1) / nwaves);
+
+  const T *wp[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    int n = n0 + (a % RPW) * 16 + r16;
+    n = n < p.N ? n : p.N - 1;  // ragged last tile: re-read the last row, dropped at the store
+    if (GATED && a >= RPW) n += p.N;
+    wp[a] = (const T *)p.w + (int64_t)n * p.K + g * 8;
+  }
+  const T *xp[MT];
+#pragma unroll
+  for (int b = 0; b < MT; ++b) {
+    int m = b * 16 + r16;
+    m = m < p.M ? m : p.M - 1;
+    xp[b] = (const T *)p.x + (int64_t)m * p.x_stride + g * 8;
+  }
+
+  f32x4 acc[NA][MT];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // blocks of kUnroll k-steps, all loads of a block issued before its first MFMA; the last block of a
+  // slice is shifted back to end at the slice's end and feeds zeros for the steps already done (no
+  // serial tail; the host guarantees K/32 >= kUnroll so the shifted window stays inside the row)
+  for (int s = s_lo; s < s_hi; s += kUnroll) {
+    int sb = s + kUnroll <= s_hi ? s : s_hi - kUnroll;
+    sb = sb < 0 ? 0 : sb;
+    u32x4 wf[kUnroll][NA], xf[kUnroll][MT];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a) wf[u][a] = *(const u32x4 *)(wp[a] + sb * 32 + u * 32);
+#pragma unroll
+      for (int b = 0; b < MT; ++b) xf[u][b] = *(const u32x4 *)(xp[b] + sb * 32 + u * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      if (sb + u < s || sb + u >= s_hi) {
+#pragma unroll
+        for (int b = 0; b < MT; ++b) xf[u][b] = u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = mfma16<Tag>(wf[u][a], xf[u][b], acc[a][b]);
+    }
+  }
+
+  // partial tiles -> LDS, then output tile t of the workgroup is finished by wave t % nwaves
+  constexpr int NT = NA * MT;
+  f32x4 *red4 = (f32x4 *)red;
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) red4[(wave * NT + a * MT + b) * 64 + lane] = acc[a][b];
+  __syncthreads();
+  auto tile_sum = [&](int t) {
+    f32x4 sum = red4[t * 64 + lane];
+    for (int w = 1; w < nwaves; ++w) {
+      const f32x4 v = red4[(w * NT + t) * 64 + lane];
+      sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+    }
+    return sum;
+  };
+  for (int t = wave; t < RPW * MT; t += nwaves) {
+    const int a = t / MT, b = t % MT;
+    // C layout: lane holds W rows n = g*4 + {0..3} (consecutive outputs) of token m = r16
+    const int m = b * 16 + r16, n = n0 + a * 16 + g * 4;
+    const f32x4 sum = tile_sum(t);
+    float o[4] = {sum[0], sum[1], sum[2], sum[3]};
+    if constexpr (GATED) {
+      const f32x4 up = tile_sum(t + RPW * MT);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float gt = elem<Tag>::ld(elem<Tag>::st(o[i]));  // the GEMM output as the unfused path stores it
+        const float ut = elem<Tag>::ld(elem<Tag>::st(up[i]));
+        float sl = gt / (1.0f + expf(-gt));                     // rmsnorm.hip: silu_and_mul_kernel
+        sl = elem<Tag>::ld(elem<Tag>::st(sl));
+        o[i] = __fmul_rn(sl, ut);
+      }
+    }
+    if (m < p.M && n < p.N) {
+      if (!GATED && p.bias) {
+        const T *bp = (const T *)p.bias + n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] += elem<Tag>::ld(bp[i]);
+      }
+      u32x2 pk;
+      pk[0] = (uint32_t)elem<Tag>::st(o[0]) | ((uint32_t)elem<Tag>::st(o[1]) << 16);
+      pk[1] = (uint32_t)elem<Tag>::st(o[2]) | ((uint32_t)elem<Tag>::st(o[3]) << 16);
+      *(u32x2 *)((T *)p.out + (int64_t)m * p.out_stride + n) = pk;
+    }
+  }
+}
+
+template <typename Tag, int RPW, bool GATED>
+int launch_mt_(const LinearParams &p, int mt, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+  switch (mt) {
+    case 1: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 1, GATED>), grid, block, lds, stream, p); break;
+    case 2: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 2, GATED>), grid, block, lds, stream, p); break;
+    case 3: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 3, GATED>), grid, block, lds, stream, p); break;
+    default: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 4, GATED>), grid, block, lds, stream, p); break;
+  }
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+template <typename Tag, bool GATED>
+int launch(const LinearParams &p, int rpw, int mt, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+  if constexpr (!GATED)
+    if (rpw == 4) return launch_mt_<Tag, 4, GATED>(p, mt, grid, block, lds, stream);
+  if (rpw == 2) return launch_mt_<Tag, 2, GATED>(p, mt, grid, block, lds, stream);
+  return launch_mt_<Tag, 1, GATED>(p, mt, grid, block, lds, stream);
+}
+
+int env_int(const char *name) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : 0;
+}
+
+// n = output columns.  Rows per wave (RPW·16; GATED: RPW gate tiles + RPW up tiles): every workgroup
+// re-reads all of x from L2 in fragment-shaped pieces that cost the texture path as much as the weight
+// fragments do (free for M <= 2, where the 16 lanes of a row group read the same line), so wide layers
+// take 2-4 row tiles per wave.  K slices per workgroup: enough waves that the chip holds >= ~2048 of
+// them, each slice at least one full block of k-steps (two for the last doubling).  Measured choices:
+// tools/bench_linear.py --sweep.
+template <bool GATED>
+int run(const LinearParams &p, int dtype, hipStream_t st) {
+  const int m = p.M, n = p.N, mt = (m + 15) / 16, steps = p.K / 32;
+  int rpw = GATED ? (m > 2 && n >= 16384 ? 2 : 1) : (m <= 2 ? 1 : (n >= 65536 ? 4 : (n >= 8192 ? 2 : 1)));
+  const int force_rpw = env_int("MV_LINEAR_RPW");
+  if (force_rpw == 1 || force_rpw == 2 || (force_rpw == 4 && !GATED)) rpw = force_rpw;
+  const int na = GATED ? 2 * rpw : rpw;
+  const int tiles = (n + rpw * 16 - 1) / (rpw * 16);
+  const int unroll = unroll_of(na, mt);
+  int waves = 4;
+  while (waves < 16 && tiles * waves < 2048 && waves * 2 * na * mt <= 64 &&
+         steps / (waves * 2) >= (waves == 8 ? 2 * unroll : unroll))
+    waves *= 2;
+  const int force_waves = env_int("MV_LINEAR_WAVES");
+  if (force_waves >= 1 && force_waves <= 16 && force_waves * na * mt <= 64) waves = force_waves;
+  while (waves > 1 && waves * na * mt > 64) waves /= 2;  // 64 KB of LDS for the partial tiles
+  const size_t lds = (size_t)waves * na * mt * 64 * sizeof(f32x4);
+  dim3 grid(tiles), block(waves * 64);
+  return dtype == MV_BF16 ? launch<bf16_tag, GATED>(p, rpw, mt, grid, block, lds, st)
+                          : launch<f16_tag, GATED>(p, rpw, mt, grid, block, lds, st);
+}
+
+int check(const void *x, int64_t x_stride, const void *w, const void *bias, void *out, int64_t out_stride, int m,
+          int n, int k, int dtype) {
+  if (!x || !w || !out) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (m < 0 || m > 64 || n < 0 || k < 256 || (k & 31) || (n & 3)) return MV_E_SHAPE;
+  if (!mv_aligned16(x) || !mv_aligned16(w) || (((uintptr_t)out) & 7u) || (x_stride & 7) || (out_stride & 3) ||
+      (bias && (((uintptr_t)bias) & 7u)))
+    return MV_E_ALIGN;
+  return MV_OK;
+}
+
+}  // namespace
+
+extern "C" int mv_linear_small_m(const void *x, int64_t x_stride, const void *w, const void *bias, void *out,
+                                 int64_t out_stride, int m, int n, int k, int dtype, void *stream) {
+  if (m == 0 || n == 0) return MV_OK;
+  if (int e = check(x, x_stride, w, bias, out, out_stride, m, n, k, dtype)) return e;
+  LinearParams p{x, w, bias, out, x_stride, out_stride, m, n, k};
+  return run<false>(p, dtype, (hipStream_t)stream);
+}
+
+extern "C" int mv_gate_up_silu_small_m(const void *x, int64_t x_stride, const void *w_gate_up, void *out,
+                                       int64_t out_stride, int m, int n_inter, int k, int dtype, void *stream) {
+  if (m == 0 || n_inter == 0) return MV_OK;
+  if (int e = check(x, x_stride, w_gate_up, nullptr, out, out_stride, m, n_inter, k, dtype)) return e;
+  LinearParams p{x, w_gate_up, nullptr, out, x_stride, out_stride, m, n_inter, k};
+  return run<true>(p, dtype, (hipStream_t)stream);
+}

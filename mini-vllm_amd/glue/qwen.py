@@ -18,6 +18,7 @@ from torch import nn
 from .. import hip_ops
 from ..layers import (Attention, MergedColumnParallelLinear, ParallelLMHead, QKVParallelLinear, RMSNorm,
                       RowParallelLinear, SiluAndMul, VocabParallelEmbedding, get_rope)
+from ..layers.linear import small_m
 from ..parallel_state import get_tensor_parallel_world_size
 from ..utils.context import get_context
 
@@ -120,6 +121,9 @@ class QwenMLP(nn.Module):
         self.hidden_act, self.intermediate_size, self.hidden_size = hidden_act, intermediate_size, hidden_size
 
     def forward(self, x):
+        w = self.gate_up_proj.weight
+        if small_m(x, w):  # decode-sized batch: SiluAndMul in the epilogue of the weight-streaming gate_up kernel
+            return self.down_proj(hip_ops.gate_up_silu_small_m(x, w))
         return self.down_proj(self.act_fn(self.gate_up_proj(x)))
 
 

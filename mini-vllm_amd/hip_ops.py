@@ -47,6 +47,10 @@ _SIGNATURES = {
                           c_int, c_void_p]),
     "mv_decode_advance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mv_silu_and_mul": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "mv_linear_small_m": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                  c_int, c_int, c_void_p]),
+    "mv_gate_up_silu_small_m": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                        c_int, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -316,6 +320,49 @@ def silu_and_mul(x):
     _check(_lib.mv_silu_and_mul(x2.data_ptr(), x2.stride(0), out.data_ptr(), out.stride(0), x2.shape[0],
                                 cols, _dt(x), _stream()), "mv_silu_and_mul")
     return out.view(*x.shape[:-1], cols)
+
+
+# ---------------------------------------------------------------- K10
+LINEAR_SMALL_M_MAX = 64
+
+
+def linear_small_m_ok(x, weight) -> bool:
+    """True when mv_linear_small_m takes this shape (else the caller uses the library GEMM)."""
+    k = x.shape[-1]
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and weight.dtype == x.dtype
+            and weight.dim() == 2 and weight.shape[1] == k and k >= 256 and k % 32 == 0
+            and 0 < x.numel() // k <= LINEAR_SMALL_M_MAX and weight.shape[0] % 4 == 0
+            and weight.is_contiguous() and x.stride(-1) == 1 and x.data_ptr() % 16 == 0
+            and (x.dim() != 2 or x.stride(0) % 8 == 0))
+
+
+def linear_small_m(x, weight, bias=None):
+    """x [..., K] (<= 64 rows), weight [N, K], bias [N] | None -> [..., N]; fp32 accumulation."""
+    _need_cuda(x, weight)
+    x2, k = _rows2d(x)
+    n = weight.shape[0]
+    if weight.shape[1] != k or not weight.is_contiguous():
+        raise ValueError(f"weight {tuple(weight.shape)} does not match x [..., {k}]")
+    if bias is not None and (bias.dtype != x.dtype or bias.shape[0] != n):
+        raise ValueError("bias dtype/shape mismatch")
+    out = torch.empty((x2.shape[0], n), dtype=x.dtype, device=x.device)
+    _check(_lib.mv_linear_small_m(x2.data_ptr(), x2.stride(0), weight.data_ptr(), _ptr(bias), out.data_ptr(),
+                                  out.stride(0), x2.shape[0], n, k, _dt(x), _stream()), "mv_linear_small_m")
+    return out.view(*x.shape[:-1], n)
+
+
+def gate_up_silu_small_m(x, weight):
+    """x [..., K] (<= 64 rows), weight [2I, K] = [gate rows ; up rows] -> silu(x Wg^T) * (x Wu^T), [..., I]."""
+    _need_cuda(x, weight)
+    x2, k = _rows2d(x)
+    if weight.shape[0] % 2 or weight.shape[1] != k or not weight.is_contiguous():
+        raise ValueError(f"weight {tuple(weight.shape)} is not a merged [2I, {k}] gate_up matrix")
+    n = weight.shape[0] // 2
+    out = torch.empty((x2.shape[0], n), dtype=x.dtype, device=x.device)
+    _check(_lib.mv_gate_up_silu_small_m(x2.data_ptr(), x2.stride(0), weight.data_ptr(), out.data_ptr(),
+                                        out.stride(0), x2.shape[0], n, k, _dt(x), _stream()),
+           "mv_gate_up_silu_small_m")
+    return out.view(*x.shape[:-1], n)
 
 
 # ---------------------------------------------------------------- a2 (device side)

@@ -8,6 +8,7 @@ from torch import nn
 from ..parallel_state import (get_tensor_parallel_rank, get_tensor_parallel_world_size,
                               tp_all_gather_last_dim, tp_all_reduce)
 from ..utils.context import get_context
+from .linear import linear
 
 __all__ = ["VocabParallelEmbedding", "ParallelLMHead", "get_tensor_parallel_rank",
            "get_tensor_parallel_world_size"]
@@ -53,5 +54,5 @@ class ParallelLMHead(VocabParallelEmbedding):
         ctx = get_context()
         if ctx.is_prefill:  # only each sequence's last token is sampled
             x = x[(ctx.cum_seqlens_q[1:] - 1).long()].contiguous()
-        logits = F.linear(x, self.weight)
+        logits = linear(x, self.weight)
         return tp_all_gather_last_dim(logits) if self.tp_size > 1 else logits

@@ -1,17 +1,36 @@
 """Tensor-parallel linear layers (mirror of minivllm/models/layers/linear.py:36-319).
-GEMMs stay on hipBLASLt through ``F.linear``; what matters here is which slice of a checkpoint
-tensor each rank owns (the ``weight_loader`` hooks) and the all-reduce after row-parallel GEMMs."""
+GEMMs stay on hipBLASLt through ``F.linear``, except for decode steps of up to ``SMALL_M_MAX`` tokens:
+there every projection is a pure HBM stream of its weights and goes to the weight-streaming HIP kernel
+(csrc/linear_small_m.hip).  What else matters here is which slice of a checkpoint tensor each rank owns
+(the ``weight_loader`` hooks) and the all-reduce after row-parallel GEMMs."""
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import hip_ops
 from ..parallel_state import (divide, get_tensor_parallel_rank, get_tensor_parallel_world_size,
                               tp_all_reduce)
 
 __all__ = ["LinearBase", "ReplicatedLinear", "ColumnParallelLinear", "MergedColumnParallelLinear",
-           "QKVParallelLinear", "RowParallelLinear", "divide"]
+           "QKVParallelLinear", "RowParallelLinear", "divide", "linear", "small_m"]
+
+# rows up to which the weight-streaming kernel beats the library GEMM (tools/bench_linear.py); 0 disables
+SMALL_M_MAX = int(os.environ.get("MV_LINEAR_SMALL_M_MAX", "16"))
+
+
+def small_m(x, weight) -> bool:
+    return (x.is_cuda and 0 < x.numel() // x.shape[-1] <= SMALL_M_MAX and hip_ops.linear_small_m_ok(x, weight))
+
+
+def linear(x, weight, bias=None):
+    """``F.linear`` semantics; decode-sized inputs take the HIP weight-streaming kernel."""
+    if small_m(x, weight):
+        return hip_ops.linear_small_m(x, weight, bias)
+    return F.linear(x, weight, bias)
 
 
 class LinearBase(nn.Module):
@@ -44,7 +63,7 @@ class ReplicatedLinear(LinearBase):
         param.data.copy_(loaded_weight)
 
     def forward(self, x):
-        return F.linear(x, self.weight, self.bias)
+        return linear(x, self.weight, self.bias)
 
 
 class ColumnParallelLinear(LinearBase):
@@ -58,7 +77,7 @@ class ColumnParallelLinear(LinearBase):
         param.data.copy_(loaded_weight.narrow(0, self.tp_rank * shard, shard))
 
     def forward(self, x):
-        return F.linear(x, self.weight, self.bias)
+        return linear(x, self.weight, self.bias)
 
 
 class MergedColumnParallelLinear(ColumnParallelLinear):
@@ -119,5 +138,5 @@ class RowParallelLinear(LinearBase):
         param.data.copy_(loaded_weight.narrow(1, self.tp_rank * shard, shard))
 
     def forward(self, x):
-        y = F.linear(x, self.weight, self.bias if self.tp_rank == 0 else None)
+        y = linear(x, self.weight, self.bias if self.tp_rank == 0 else None)
         return tp_all_reduce(y) if self.tp_size > 1 else y

@@ -409,3 +409,69 @@ def test_sampler_degenerate_rows(H):
     toks = H.sample(d(logits), d(torch.ones(2)), d(torch.tensor([-1, -1])), d(torch.ones(2)), d(torch.zeros(2)), seed=1)
     assert 0 <= toks[0].item() < V   # all filtered -> uniform fallback (functional.py:419-429)
     assert toks[1].item() == 7
+
+
+# ------------------------------------------------------------------ K10
+def _ulp_ok(got, exact, dtype, ulps):
+    """|got - exact| <= ulps units in the last place of ``dtype`` at the magnitude of ``exact``
+    (+ one ulp of the accumulation scale for results that cancel to ~0)."""
+    eps = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    err = (got.double() - exact).abs()
+    bound = ulps * eps * exact.abs() + eps * exact.abs().mean()
+    return bool((err <= bound).all()), float((err / bound).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k,bias", [
+    (1, 2048, 2048, False), (1, 4608, 3584, True), (2, 12288, 2048, False), (3, 40, 256, True),
+    (7, 2048, 6144, False), (16, 4096, 2048, True), (17, 2064, 288, False), (33, 1000, 2048 + 32, True),
+    (64, 16384 + 16, 512, False), (5, 151936, 1024, False),
+])
+def test_linear_small_m(H, dtype, m, n, k, bias):
+    # fp32 accumulation of 16-bit products, one rounding: within 1 ulp of the exact (float64) result
+    x = _randn(m, k, dtype=dtype, seed=m + n).to(DEV)
+    w = (_randn(n, k, dtype=torch.float32, seed=n + k) * k ** -0.5).to(dtype).to(DEV)
+    b = _randn(n, dtype=dtype, seed=3).to(DEV) if bias else None
+    exact = O.linear(x.cpu(), w.cpu(), None if b is None else b.cpu())
+    got = H.linear_small_m(x, w, b)
+    assert got.shape == (m, n) and got.dtype == dtype
+    ok, worst = _ulp_ok(got.cpu(), exact, dtype, 1.0)
+    assert ok, worst
+    # strided input rows (a column block of a wider activation), as q/k/v views are
+    wide = torch.zeros(m, k + 64, dtype=dtype, device=DEV)
+    wide[:, 32:32 + k] = x
+    got2 = H.linear_small_m(wide[:, 32:32 + k], w, b)
+    assert torch.equal(got2, got)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,inter,k", [(1, 6144, 2048), (4, 18944, 3584), (16, 1000, 512), (40, 16400, 256)])
+def test_gate_up_silu_small_m(H, dtype, m, inter, k):
+    x = _randn(m, k, dtype=dtype, seed=m).to(DEV)
+    w = (_randn(2 * inter, k, dtype=torch.float32, seed=inter) * k ** -0.5).to(dtype).to(DEV)
+    got = H.gate_up_silu_small_m(x, w)
+    assert got.shape == (m, inter)
+    # the unfused pair on the GPU (same rounding points; summation order may differ by slicing)
+    unfused = H.silu_and_mul(H.linear_small_m(x, w))
+    exact_gu = O.linear(x.cpu(), w.cpu())
+    want = O.gate_up_silu(x.cpu(), w.cpu(), dtype).double()
+    # a GEMM output within 1 ulp of a rounding boundary may round either way: allow 3 ulp end to end
+    ok, worst = _ulp_ok(got.cpu(), want, dtype, 3.0)
+    assert ok, worst
+    ok, worst = _ulp_ok(got.cpu(), unfused.cpu().double(), dtype, 3.0)
+    assert ok, worst
+    assert exact_gu.shape == (m, 2 * inter)
+
+
+def test_linear_small_m_argument_errors(H):
+    x = torch.zeros(4, 256, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(64, 256, dtype=torch.bfloat16, device=DEV)
+    assert H.linear_small_m(x, w).abs().sum() == 0
+    assert H.linear_small_m(x[:0], w).shape == (0, 64)
+    for bad_x, bad_w in [(torch.zeros(65, 256, dtype=torch.bfloat16, device=DEV), w),            # M > 64
+                         (torch.zeros(4, 224, dtype=torch.bfloat16, device=DEV), w[:, :224].contiguous()),  # K < 256
+                         (x.float(), w.float())]:                                                  # fp32
+        with pytest.raises(H.MvHipError):
+            H.linear_small_m(bad_x, bad_w)
+        assert not H.linear_small_m_ok(bad_x, bad_w)
+    assert H.linear_small_m_ok(x, w)
