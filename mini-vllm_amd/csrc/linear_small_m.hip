@@ -47,7 +47,8 @@ struct LinearParams {
 __host__ __device__ constexpr int unroll_of(int rpw, int mt) { return rpw + mt <= 2 ? 8 : (rpw + mt <= 5 ? 4 : 2); }
 
 template <typename Tag, int RPW, int MT, bool GATED>
-__global__ void __launch_bounds__(1024) linear_small_m_kernel(LinearParams p) {
+__global__ void __launch_bounds__((GATED ? 2 : 1) * RPW * MT >= 12 ? 512 : 1024)
+linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of partial-tile LDS allow <= 5 waves)
   typedef uint16_t T;
   extern __shared__ float red[];  // [waves][RPW*MT][64][4]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
