@@ -21,7 +21,7 @@ import torch
 
 from ..config import Config
 from ..layers.sampler import Sampler
-from ..parallel_state import get_tensor_parallel_world_size
+from ..parallel_state import get_tensor_parallel_world_size, tp_merge_greedy
 from ..utils.context import reset_context, set_context
 from .. import hip_ops
 from .input_builder import BatchInputs, InputBuilder
@@ -50,7 +50,7 @@ class InferenceExecutor:
         self.device = device if device is not None else next(model.parameters()).device
         self.block_size = config.kvcache_block_size
         hf = config.hf_config
-        tp = get_tensor_parallel_world_size()
+        tp = self.tp_size = get_tensor_parallel_world_size()
         total_kv = getattr(hf, "num_key_value_heads", getattr(hf, "num_attention_heads", 1))
         self.num_kv_heads = max(total_kv // tp, 1)
         self.head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
@@ -63,6 +63,7 @@ class InferenceExecutor:
         self.kv_cache: torch.Tensor | None = None
         self.sampler: Sampler | None = None
         self.graphs: dict[int, torch.cuda.CUDAGraph] = {}
+        self.greedy_graphs: dict[int, torch.cuda.CUDAGraph] = {}   # TP > 1: per-rank argmax instead of the logit gather
         self.graph_bs: list[int] = []
         self.graph_vars: dict[str, torch.Tensor] = {}
         self.graph_pool = None
@@ -181,7 +182,9 @@ class InferenceExecutor:
     # ------------------------------------------------------------------ one step
     @torch.inference_mode()
     def execute_batch(self, sequences: list[Sequence], prefill: bool = True):
-        """-> (logits [n, V], next_tokens list[int])."""
+        """-> (logits [n, V], next_tokens list[int]).  Under tensor parallelism an all-greedy batch is
+        decoded from per-rank argmaxes (parallel_state.tp_merge_greedy) and ``logits`` is then this rank's
+        vocab shard [n, V/tp]: the full-logit all-gather is the largest message of a decode step."""
         if not sequences:
             return torch.empty(0, device=self.device), []
         try:
@@ -189,8 +192,9 @@ class InferenceExecutor:
                 self._spec = None  # a speculative decode step in flight (if any) is simply ignored
                 inp = self.builder.prefill(sequences)
                 ids, pos = self._ship_prefill(inp, sequences)
-                logits = self.model.compute_logits(self.model(ids, pos))
-                tokens = self._sample_tokens(logits, sequences)
+                greedy = self._tp_greedy(sequences)
+                logits = self.model.compute_logits(self.model(ids, pos), gather=not greedy)
+                tokens = self._sample_tokens(logits, sequences, tp_greedy=greedy)
             else:
                 bs = self._graph_bucket(len(sequences))
                 inp = self.builder.decode(sequences, pad_to=bs)
@@ -198,8 +202,9 @@ class InferenceExecutor:
                     logits, tokens = self._replay_graph(bs, inp, sequences)
                 else:
                     ids, pos = self._ship_decode(inp)
-                    logits = self.model.compute_logits(self.model(ids, pos))
-                    tokens = self._sample_tokens(logits, sequences)
+                    greedy = self._tp_greedy(sequences)
+                    logits = self.model.compute_logits(self.model(ids, pos), gather=not greedy)
+                    tokens = self._sample_tokens(logits, sequences, tp_greedy=greedy)
             self._update_metrics(sequences, prefill)
             self.inference_count += 1
             return logits, tokens
@@ -256,7 +261,17 @@ class InferenceExecutor:
         d = self._dev_samp_f32
         return d[0, :n], self._dev_samp_i64[:n], d[1, :n], d[2, :n]
 
-    def _sample_tokens(self, logits, sequences) -> list[int]:
+    def _tp_greedy(self, sequences) -> bool:
+        return self.tp_size > 1 and self.sampler is not None and all(s.temperature == 0 for s in sequences)
+
+    def _greedy_merge(self, logits_local, t, k, p, m):
+        """Tokens of an all-greedy batch from this rank's vocab shard (temperature 0 rows: the sampler
+        kernel returns the lowest-index argmax of the shard)."""
+        local = self.sampler(logits_local, temperatures=t, top_ks=k, top_ps=p, min_ps=m)
+        vals = logits_local.gather(1, local.unsqueeze(1)).squeeze(1)
+        return tp_merge_greedy(local, vals, logits_local.shape[1])
+
+    def _sample_tokens(self, logits, sequences, tp_greedy: bool = False) -> list[int]:
         if self.sampler is None:
             return []
         if len(sequences) > self._samp_i64.shape[0]:
@@ -267,6 +282,8 @@ class InferenceExecutor:
             m = torch.tensor([s.min_p for s in sequences], dtype=torch.float32, device=dev)
         else:
             t, k, p, m = self._ship_sampling(sequences)
+        if tp_greedy:
+            return self._greedy_merge(logits, t, k, p, m).tolist()
         return self.sampler(logits, temperatures=t, top_ks=k, top_ps=p, min_ps=m).tolist()
 
     def _update_metrics(self, sequences, prefill: bool) -> None:
@@ -303,6 +320,8 @@ class InferenceExecutor:
             "slot_mapping": self._dev_slots[:max_bs], "context_lens": self._dev_ctx[:max_bs],
             "block_tables": self._dev_tables[:max_bs],
             "logits": torch.zeros((max_bs, vocab), dtype=self.dtype, device=dev),
+            "logits_local": (torch.zeros((max_bs, vocab // self.tp_size), dtype=self.dtype, device=dev)
+                             if self.tp_size > 1 else None),
             "tokens": torch.zeros(max_bs, dtype=torch.int64, device=dev),
             "rng_offset": self._dev_rng[:1],
         }
@@ -315,12 +334,15 @@ class InferenceExecutor:
         self.sampler.offset_dev = gv["rng_offset"]
         try:
             for bs in reversed(self.graph_bs):
-                self._capture_one(bs)
-            logger.info("Captured %d decode graphs (batch sizes %s..%d)", len(self.graphs),
+                self._capture_one(bs, greedy=False)
+                if self.tp_size > 1:
+                    self._capture_one(bs, greedy=True)
+            logger.info("Captured %d decode graphs (batch sizes %s..%d)", len(self.graphs) + len(self.greedy_graphs),
                         self.graph_bs[:4], self.graph_bs[-1])
         except Exception as e:  # fall back to eager, loudly
             logger.warning("Failed to capture device graphs, decoding eagerly: %s", e)
             self.graphs.clear()
+            self.greedy_graphs.clear()
             self.graph_pool = None
             self.sampler.offset_dev = None
             reset_context()
@@ -332,34 +354,41 @@ class InferenceExecutor:
             except Exception:  # the invalidated capture reports once more; the device itself is fine
                 pass
 
-    def _graph_forward(self, bs: int):
+    def _graph_forward(self, bs: int, greedy: bool = False):
         gv = self.graph_vars
         set_context(False, 0, 0, None, None, gv["slot_mapping"][:bs], gv["context_lens"][:bs],
                     gv["block_tables"][:bs])
         hidden = self.model(gv["input_ids"][:bs], gv["positions"][:bs])
-        logits = self.model.compute_logits(hidden)
-        gv["logits"][:bs].copy_(logits)
         d = self._dev_samp_f32
-        toks = hip_ops.sample(gv["logits"][:bs], d[0, :bs], self._dev_samp_i64[:bs], d[1, :bs], d[2, :bs],
-                              seed=self.sampler.seed, offset=0, offset_dev=gv["rng_offset"])
+        if greedy:  # TP > 1, every row at temperature 0: merge per-rank argmaxes, no logit gather
+            out = gv["logits_local"][:bs]
+            out.copy_(self.model.compute_logits(hidden, gather=False))
+            local = hip_ops.sample(out, d[0, :bs], self._dev_samp_i64[:bs], d[1, :bs], d[2, :bs],
+                                   seed=self.sampler.seed, offset=0, offset_dev=gv["rng_offset"])
+            toks = tp_merge_greedy(local, out.gather(1, local.unsqueeze(1)).squeeze(1), out.shape[1])
+        else:
+            out = gv["logits"][:bs]
+            out.copy_(self.model.compute_logits(hidden))
+            toks = hip_ops.sample(out, d[0, :bs], self._dev_samp_i64[:bs], d[1, :bs], d[2, :bs],
+                                  seed=self.sampler.seed, offset=0, offset_dev=gv["rng_offset"])
         gv["tokens"][:bs].copy_(toks)
         # last node: advance the device-side decode inputs so that the NEXT step can be replayed as is
         hip_ops.decode_advance(gv["input_ids"][:bs], gv["tokens"][:bs], gv["positions"][:bs],
                                gv["slot_mapping"][:bs], gv["context_lens"][:bs], gv["rng_offset"])
 
     @torch.inference_mode()
-    def _capture_one(self, bs: int) -> None:
+    def _capture_one(self, bs: int, greedy: bool = False) -> None:
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):  # warm-up on a side stream (RCCL / hipBLASLt lazy init)
-            self._graph_forward(bs)
+            self._graph_forward(bs, greedy)
         torch.cuda.current_stream(self.device).wait_stream(s)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, pool=self.graph_pool):
-            self._graph_forward(bs)
+            self._graph_forward(bs, greedy)
         if self.graph_pool is None:
             self.graph_pool = graph.pool()
-        self.graphs[bs] = graph
+        (self.greedy_graphs if greedy else self.graphs)[bs] = graph
         torch.cuda.synchronize(self.device)
         reset_context()
 
@@ -378,11 +407,14 @@ class InferenceExecutor:
         with identical values or that belong to finished sequences."""
         b = inp.num_seqs
         gv = self.graph_vars
+        greedy = bs in self.greedy_graphs and self._tp_greedy(sequences)
+        graph = self.greedy_graphs[bs] if greedy else self.graphs[bs]
         spec, self._spec = self._spec, None
         hit = False
         if spec is not None:
-            batch, sbs, lens, slot = spec
-            hit = (sbs == bs and len(batch) == b and not inp.tables_dirty and not inp.batch_changed
+            batch, sbs, lens, slot, sgraph = spec
+            hit = (sbs == bs and sgraph is graph and len(batch) == b and not inp.tables_dirty
+                   and not inp.batch_changed
                    and all(x is y for x, y in zip(batch, sequences))
                    and all(s.num_tokens == n for s, n in zip(sequences, lens)))
             self.spec_hits += hit
@@ -397,14 +429,14 @@ class InferenceExecutor:
             if w and inp.tables_dirty:
                 self._dev_tables[:b, :w].copy_(inp.block_tables, non_blocking=True)
             self._ship_sampling(sequences, b_pad=bs, unchanged=not inp.batch_changed)
-            self.graphs[bs].replay()
+            graph.replay()
             slot_now = self._stash_tokens(b)
         if self.speculate_next and self._can_speculate(sequences):
             self.sampler.calls += 1                          # the graph advanced the device-side offset itself
-            self.graphs[bs].replay()
-            self._spec = (list(sequences), bs, [s.num_tokens + 1 for s in sequences], self._stash_tokens(b))
+            graph.replay()
+            self._spec = (list(sequences), bs, [s.num_tokens + 1 for s in sequences], self._stash_tokens(b), graph)
         self._tok_events[slot_now].synchronize()
-        return gv["logits"][:b], self._tok_host[slot_now][:b].tolist()
+        return (gv["logits_local"] if greedy else gv["logits"])[:b], self._tok_host[slot_now][:b].tolist()
 
     def _stash_tokens(self, b: int) -> int:
         """Async D2H of the step that was just enqueued into a pinned ring slot + an event to wait on."""
@@ -425,6 +457,7 @@ class InferenceExecutor:
 
     def cleanup(self) -> None:
         self.graphs.clear()
+        self.greedy_graphs.clear()
         self.graph_vars.clear()
         self.graph_pool = None
         self.kv_cache = None

@@ -120,8 +120,8 @@ class OPTForCausalLM(nn.Module):
     def forward(self, input_ids, positions):
         return self.model(input_ids, positions)
 
-    def compute_logits(self, hidden_states):
-        return self.lm_head(hidden_states)
+    def compute_logits(self, hidden_states, gather: bool = True):
+        return self.lm_head(hidden_states, gather=gather)
 
     def set_kv_cache(self, kv_cache) -> None:
         for layer, (k, v) in zip(self.model.decoder.layers, kv_cache):

@@ -50,9 +50,11 @@ class ParallelLMHead(VocabParallelEmbedding):
             raise ValueError("bias for ParallelLMHead is not supported")
         super().__init__(num_embeddings, embedding_dim)
 
-    def forward(self, x):
+    def forward(self, x, gather: bool = True):
+        """``gather=False`` returns this rank's vocab shard ``[B, V/tp]`` (greedy decoding merges
+        per-rank argmaxes instead of gathering the logits: parallel_state.tp_merge_greedy)."""
         ctx = get_context()
         if ctx.is_prefill:  # only each sequence's last token is sampled
             x = x[(ctx.cum_seqlens_q[1:] - 1).long()].contiguous()
         logits = linear(x, self.weight)
-        return tp_all_gather_last_dim(logits) if self.tp_size > 1 else logits
+        return tp_all_gather_last_dim(logits) if self.tp_size > 1 and gather else logits

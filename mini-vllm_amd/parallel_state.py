@@ -39,6 +39,23 @@ def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def tp_all_gather_stack(x: torch.Tensor) -> torch.Tensor:
+    """``[tp, *x.shape]``: every rank's ``x``, rank-major, on every rank."""
+    n = _state["size"]
+    if n == 1:
+        return x.unsqueeze(0)
+    if x.is_cuda and dist.get_backend(_state["group"]) == "gloo":
+        # gloo has no device all-gather; only the 2-process single-GPU TP test takes this path
+        out = torch.zeros((n,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        out[_state["rank"]] = x
+        dist.all_reduce(out, group=_state["group"])
+        return out
+    x = x.contiguous()
+    flat = torch.empty((n * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(flat, x, group=_state["group"])  # rank-major along dim 0
+    return flat.view((n,) + tuple(x.shape))
+
+
 def tp_all_gather_last_dim(x: torch.Tensor) -> torch.Tensor:
     """Concatenate vocab shards along the last dim on EVERY rank (C3).  The reference gathers to
     rank 0 only (embed_head.py:219-229); here all ranks run the same scheduler and sampler, so
@@ -46,17 +63,20 @@ def tp_all_gather_last_dim(x: torch.Tensor) -> torch.Tensor:
     n = _state["size"]
     if n == 1:
         return x
-    if x.is_cuda and dist.get_backend(_state["group"]) == "gloo":
-        # gloo has no device all-gather; only the 2-process single-GPU TP test takes this path
-        out = torch.zeros((n,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        out[_state["rank"]] = x
-        dist.all_reduce(out, group=_state["group"])
-    else:
-        x = x.contiguous()
-        flat = torch.empty((n * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(flat, x, group=_state["group"])  # rank-major along dim 0
-        out = flat.view((n,) + tuple(x.shape))
-    return out.movedim(0, -2).reshape(*x.shape[:-1], n * x.shape[-1])
+    return tp_all_gather_stack(x).movedim(0, -2).reshape(*x.shape[:-1], n * x.shape[-1])
+
+
+def tp_merge_greedy(local_tokens: torch.Tensor, local_values: torch.Tensor, vocab_per_rank: int) -> torch.Tensor:
+    """Greedy decoding without the full-logit gather: each rank brings the argmax of its
+    vocab shard (shard-local index, lowest on ties) and its value; the row's token is the global index
+    of the largest value, the lowest global index on ties -- exactly ``argmax`` of the gathered row.
+    One all-gather of B x 16 bytes per rank instead of B x V/tp logits."""
+    gidx = local_tokens + _state["rank"] * vocab_per_rank
+    pair = torch.stack((local_values.double(), gidx.double()), dim=-1)      # exact for 16/32-bit logits
+    allp = tp_all_gather_stack(pair)                                          # [tp, B, 2]
+    vals, idx = allp[..., 0], allp[..., 1]
+    best = vals.max(dim=0, keepdim=True).values
+    return torch.where(vals == best, idx, torch.full_like(idx, float("inf"))).min(dim=0).values.long()
 
 
 def divide(numerator: int, denominator: int) -> int:

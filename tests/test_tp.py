@@ -80,6 +80,22 @@ def _layers_worker(rank, world, port, out_path):
     ids = torch.tensor([0, 39, 20, 19, 7])
     res["emb"] = (emb(ids), F.embedding(ids, table))
     res["head"] = (head(x), F.linear(x, table))
+    # greedy decoding from per-rank argmaxes == argmax of the gathered row (lowest index on ties,
+    # within a shard and across shards), without gathering the logits
+    from minivllm_amd.parallel_state import tp_merge_greedy
+
+    full = F.linear(x, table)
+    full[1, 3], full[1, 27] = full[1].max() + 1, full[1].max() + 1      # tie across the two shards
+    full[2, 30], full[2, 35] = full[2].max() + 2, full[2].max() + 2     # tie inside the last shard
+    full[3] = 0.25                                                       # every entry ties
+    vl = 40 // world
+    shard = full[:, rank * vl:(rank + 1) * vl]
+    assert torch.equal(head(x, gather=False), F.linear(x, table)[:, rank * vl:(rank + 1) * vl])
+    local = shard.argmax(dim=1)          # torch's CPU argmax returns the first maximum
+    merged = tp_merge_greedy(local, shard.gather(1, local[:, None])[:, 0], vl)
+    want = torch.tensor([int(torch.nonzero(r == r.max())[0]) for r in full])
+    assert merged.dtype == torch.int64 and torch.equal(merged, want), (merged, want)
+    assert merged[1] == 3 and merged[2] == 30 and merged[3] == 0
     with pytest.raises(ValueError):
         VocabParallelEmbedding(41, 8)
     with pytest.raises(ValueError):
@@ -163,8 +179,17 @@ def _e2e_worker(rank, world, port, golden, workdir, out_path):
         logits, _ = ex.execute_batch(seqs, prefill=False)
         errs.append((logits.float().cpu() - torch.from_numpy(z[f"f32_decode_logits_{step}"])).abs().max().item())
     scale = float(np.abs(z["f32_prefill_logits"]).max())
+    # all-greedy batch: tokens come from per-rank argmaxes (no logit gather) and equal the argmax of the
+    # gathered row; the executor then returns this rank's vocab shard
+    full = logits
+    for s in seqs:
+        s.temperature = 0.0
+    shard, toks = ex.execute_batch(seqs, prefill=False)
+    vl = full.shape[1] // world
+    greedy_ok = (shard.shape == (len(seqs), vl) and torch.equal(shard, full[:, rank * vl:(rank + 1) * vl])
+                 and toks == full.argmax(dim=-1).tolist())
     dist.barrier()
-    open(out_path + f".{rank}", "w").write(json.dumps(dict(errs=errs, scale=scale)))
+    open(out_path + f".{rank}", "w").write(json.dumps(dict(errs=errs, scale=scale, greedy_ok=bool(greedy_ok))))
     dist.destroy_process_group()
 
 
@@ -178,3 +203,4 @@ def test_tp2_logits_match_reference_on_one_gpu(golden_dir, tmp_path):
     for rank in (0, 1):                                 # SPMD: every rank holds the full logits
         r = json.loads(open(out + f".{rank}").read())
         assert max(r["errs"]) <= 2e-4 * r["scale"], r
+        assert r["greedy_ok"], r
