@@ -65,7 +65,9 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
   char *ldsV = smem + TILE_BYTES;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  // the wave index as a SCALAR: everything derived from it (the diagonal test below) then branches on
+  // scc instead of being if-converted into 100 predicated VALU instructions on every tile
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int g = (lane >> 4) & 1, i16 = lane & 15;
 
@@ -118,6 +120,10 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
   const int64_t vstride = paged ? (int64_t)p.n_kv_heads * D : p.v_stride;
   u32x4 kreg[4], vreg[4];
   bool tile_ok_next = true;
+  // thread (row tid/16, chunk tid%16) + 16 rows per i: the per-thread byte offset is loop invariant, the
+  // tile base and the 16-row steps are wave-uniform (scalar registers)
+  const uint32_t thr_k = (uint32_t)(((tid >> 4) * kstride + (tid & 15) * 8) * 2);
+  const uint32_t thr_v = (uint32_t)(((tid >> 4) * vstride + (tid & 15) * 8) * 2);
   auto fetch = [&](int t) {
     const int kv0 = t * BN;
     int64_t base_row = k0 + kv0;  // row index into the K/V source of key kv0
@@ -128,13 +134,23 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
       tile_ok_next = blk >= 0 && blk < p.num_blocks;  // a hole: read block 0, mask the whole tile
       base_row = (int64_t)(tile_ok_next ? blk : 0) * p.block_size + (kv0 - bi * p.block_size);
     }
+    const char *kt = (const char *)(ksrc + base_row * kstride + hkv * D);
+    const char *vt = (const char *)(vsrc + base_row * vstride + hkv * D);
     const int last = sk - 1 - kv0;  // last valid row of this tile (>= 0: the tile starts inside the sequence)
+    if (last >= BN - 1) {           // full tile (all but the last one): no per-row clamp, no address math
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pc = tid + 256 * i;
-      const int row = min(pc >> 4, last), ch = pc & 15;
-      kreg[i] = *reinterpret_cast<const u32x4 *>(ksrc + (base_row + row) * kstride + hkv * D + ch * 8);
-      vreg[i] = *reinterpret_cast<const u32x4 *>(vsrc + (base_row + row) * vstride + hkv * D + ch * 8);
+      for (int i = 0; i < 4; ++i) {
+        kreg[i] = *reinterpret_cast<const u32x4 *>(kt + (int64_t)i * 32 * kstride + thr_k);
+        vreg[i] = *reinterpret_cast<const u32x4 *>(vt + (int64_t)i * 32 * vstride + thr_v);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pc = tid + 256 * i;
+        const int row = min(pc >> 4, last), ch = pc & 15;
+        kreg[i] = *reinterpret_cast<const u32x4 *>(kt + ((int64_t)row * kstride + ch * 8) * 2);
+        vreg[i] = *reinterpret_cast<const u32x4 *>(vt + ((int64_t)row * vstride + ch * 8) * 2);
+      }
     }
   };
   auto stage = [&](int buf) {
@@ -217,17 +233,20 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
     }
-    const float neg_m = -m_run;
-    float rs = 0.f;
+    // two scores per instruction where the ISA has a packed form (v_pk_fma_f32 / v_pk_add_f32)
+    const f32x2 sc2 = {scale_log2, scale_log2}, nm2 = {-m_run, -m_run};
+    f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][i], scale_log2, neg_m));
-        sacc[kt][i] = e;
-        rs += e;
+      for (int i = 0; i < 16; i += 2) {
+        const f32x2 x = __builtin_elementwise_fma(f32x2{sacc[kt][i], sacc[kt][i + 1]}, sc2, nm2);
+        const f32x2 e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+        sacc[kt][i] = e.x;
+        sacc[kt][i + 1] = e.y;
+        rs2 += e;
       }
-    l_run += rs;
+    l_run += rs2.x + rs2.y;
 
     // ---- P^T as MFMA B operand: registers 8*s2 .. 8*s2+7 of a 32-key tile are k-step s2
     u32x4 pf[2][2];

@@ -71,8 +71,15 @@ def bench_sampler(B, V, temp, top_k, top_p, min_p=0.0, dtype=torch.bfloat16):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--prefill-only", action="store_true")
     a = ap.parse_args()
     print(torch.cuda.get_device_name(0))
+    if a.prefill_only:
+        bench_prefill(16, 1024, 16, 8)
+        bench_prefill(16, 1024, 28, 4)
+        bench_prefill(4, 4096, 28, 4)
+        bench_prefill(64, 256, 28, 4)
+        raise SystemExit(0)
     bench_decode(256, 16, 8, 128, 1024)          # Qwen3-1.7B headline
     bench_prefill(16, 1024, 16, 8)               # Qwen3-1.7B, one 16384-token batch
     bench_prefill(16, 1024, 28, 4)               # Qwen2-7B config 4
