@@ -234,6 +234,14 @@ def main():
         roof = decode_roofline(engine, args)
         ex = engine.model_runner.inference_executor
         graphs = bool(ex.graphs)
+        allreduce = None
+        if args.gpus > 1:
+            from minivllm_amd import parallel_state
+
+            ar = parallel_state._state.get("custom_ar")
+            allreduce = "rccl" if ar is None else (
+                f"p2p two-shot kernel (validated against the backend at start-up, {ar.calls} calls)"
+                if ar.status() == 0 else "p2p two-shot kernel: A PEER WAIT TIMED OUT, RESULT INVALID")
         kv_blocks = engine.config.num_kvcache_blocks
         engine.exit()
     if rank != 0:
@@ -247,7 +255,7 @@ def main():
         "config": {"workload": f"{args.model} decode, B={args.batch}, ctx={args.ctx}, kvcache_block_size=64, "
                                f"max_num_seqs={args.batch}, {'hipGraph' if graphs else 'eager'} decode, greedy",
                    "model": args.model, "global_batch": args.batch, "seq_len": args.ctx,
-                   "parallelism": f"tp{args.gpus}", "kv_blocks": kv_blocks,
+                   "parallelism": f"tp{args.gpus}", "allreduce": allreduce, "kv_blocks": kv_blocks,
                    "prefill": "synthetic KV" if args.synthetic_kv else "engine prefill"},
         "prefill_tokens_per_s": None if prefill_tps is None else round(prefill_tps, 1),
         "roofline": roof, "cpu_baseline": cpu,

@@ -191,6 +191,32 @@ int mv_gate_up_silu_small_m(const void *x, int64_t x_stride, const void *w_gate_
                             void *out, int64_t out_stride, int m, int n_inter,
                             int k, int dtype, void *stream);
 
+/* C1 — small-message all-reduce over xGMI peer-to-peer loads, for the [tokens, hidden] sums of a
+ * tensor-parallel decode step.  Replaces dist.all_reduce in RowParallelLinear.forward and
+ * VocabParallelEmbedding.forward (minivllm/models/layers/linear.py:316-318, layers/embed_head.py:170-173)
+ * for 16-bit messages of at most max_bytes; larger ones (prefill) stay on RCCL.
+ * Protocol (two-shot, one launch, bounded waits): mini-vllm_amd/csrc/allreduce.hip.
+ * Set-up, on every rank (the host exchanges the handles, e.g. through the process group):
+ *   mv_ar_alloc(max_bytes, &base)            one uncached region of mv_ar_region_bytes(max_bytes)
+ *   mv_ar_ipc_export(base, handle)           mv_ar_ipc_handle_bytes() bytes, sent to every peer
+ *   mv_ar_ipc_open(peer_handle, &peer_base)  for every peer
+ * Per call: bases[world] = the region of every rank as mapped HERE (bases[rank] = own base).
+ * mv_ar_all_reduce: out = sum over ranks of x (x == out allowed), n elements, n % (8*world) == 0, fp32
+ * accumulation in rank order, identical bits on every rank.  These four are the only entry points of the
+ * library that allocate or synchronise (set-up / tear-down / status only, never on the data path). */
+size_t mv_ar_region_bytes(size_t max_bytes);
+int mv_ar_max_world(void);
+int mv_ar_alloc(size_t max_bytes, void **base_out);
+int mv_ar_free(void *base);
+int mv_ar_ipc_handle_bytes(void);
+int mv_ar_ipc_export(void *base, void *handle_out);
+int mv_ar_ipc_open(const void *handle, void **ptr_out);
+int mv_ar_ipc_close(void *ptr);
+/* 0 while every peer wait so far was satisfied (a wait that gave up sets it; results are then invalid) */
+int mv_ar_status(void *base, size_t max_bytes, uint32_t *status_out);
+int mv_ar_all_reduce(const void *x, void *out, int64_t n, void *const *bases,
+                     int rank, int world, size_t max_bytes, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,244 @@
+// C1 (SURVEY §8 b: mv_allreduce_*) — small-message all-reduce over xGMI peer-to-peer loads, for the
+// [tokens, hidden] sums after o_proj / down_proj of a tensor-parallel decode step
+// (minivllm/models/layers/linear.py:316-318 calls dist.all_reduce; RCCL's ring needs 2(W-1) latency-bound
+// steps for a 1-2 MB message).  Two-shot, one launch, no host involvement, hipGraph-capturable:
+//
+//   every rank owns one UNCACHED device region, IPC-mapped by all peers:
+//       staging[2][max_bytes] | flags[2 parities][2 phases][W ranks][NB blocks] | epoch, status
+//   call number e (read from the region, so a replayed graph advances it), parity p = e & 1:
+//     0. block b copies sub-chunk b of every slice of x into its own staging[p]
+//     1. barrier(phase 0) with block b of every peer: "my sub-chunks b are in place"
+//     2. block b of rank r sums sub-chunk b of slice r over all W ranks (fp32, rank order) and writes the
+//        rounded result back into ITS OWN staging[p] (nobody else reads slice r of rank r's staging)
+//     3. barrier(phase 1): "my reduced sub-chunk b is in place"
+//     4. block b gathers sub-chunk b of slice j from rank j, for all j, into out
+//   staging[p] is rewritten two calls later; a peer can only be two calls ahead after passing the
+//   barriers of the call in between, i.e. after every rank finished reading — no trailing barrier.
+//
+// Cross-GPU visibility does not rely on cache state: the region is allocated uncached
+// (hipDeviceMallocUncached), peer data is read with system-scope (sc0 sc1) loads, flags are
+// system-scope atomics, and a system-scope fence separates data from flag on both sides.
+// Every wait is BOUNDED: a peer that never arrives makes the kernel give up, set status != 0 and finish
+// (the host checks status after its validation run and falls back to RCCL) — the grid always drains.
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxWorld = 8;
+constexpr int kArBlocks = 32;       // workgroups per launch (= flag slots per rank and phase)
+constexpr int kArThreads = 512;
+constexpr int kSpinLimit = 4000000;  // bounded wait: ~seconds of polling, then give up
+
+struct ArRegion {
+  // byte offsets inside a rank's region
+  size_t staging_bytes;  // per parity
+  size_t flags_off, epoch_off, status_off, total;
+};
+
+__host__ __device__ inline ArRegion ar_layout(size_t max_bytes) {
+  ArRegion r;
+  r.staging_bytes = (max_bytes + 255) & ~(size_t)255;
+  r.flags_off = 2 * r.staging_bytes;
+  const size_t flags_bytes = (size_t)2 * 2 * kMaxWorld * kArBlocks * sizeof(uint32_t);
+  r.epoch_off = r.flags_off + flags_bytes;
+  r.status_off = r.epoch_off + 256;
+  r.total = r.status_off + 256;
+  return r;
+}
+
+struct ArParams {
+  char *base[kMaxWorld];  // base[rank] = own region, base[q] = peer q's region mapped here
+  const void *x;
+  void *out;
+  size_t max_bytes;
+  int64_t n;  // elements
+  int rank, world;
+};
+
+// system-scope (sc0 sc1) 16-byte load through a buffer descriptor: the compiler tracks its completion
+// itself, so the W loads of one reduction step are all in flight before the first is consumed
+typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t rsrc_t;
+__device__ __forceinline__ auto make_rsrc(char *base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+}
+template <typename R>
+__device__ __forceinline__ u32x4 load_sys(R rsrc, uint32_t byte_off) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, /*sc0|sc1*/ 17));
+}
+
+__device__ __forceinline__ uint32_t *flag_ptr(char *base, const ArRegion &L, int parity, int phase, int src, int blk) {
+  return (uint32_t *)(base + L.flags_off) + (((parity * 2 + phase) * kMaxWorld + src) * kArBlocks + blk);
+}
+
+// Block-level barrier with the same block of every peer.  Thread q < world handles peer q.
+__device__ __forceinline__ void peer_barrier(const ArParams &p, const ArRegion &L, int parity, int phase,
+                                             uint32_t epoch, uint32_t *status) {
+  __threadfence_system();  // this thread's staging stores are performed before the flag goes out
+  __syncthreads();
+  const int q = threadIdx.x;
+  if (q < p.world) {
+    if (q != p.rank)
+      __hip_atomic_store(flag_ptr(p.base[q], L, parity, phase, p.rank, blockIdx.x), epoch, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    if (q != p.rank) {
+      uint32_t *mine = flag_ptr(p.base[p.rank], L, parity, phase, q, blockIdx.x);
+      int spins = 0;
+      // epochs only grow; a flag from a later call (>= epoch + 2, same parity) also means "arrived"
+      while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+        if (++spins > kSpinLimit) {
+          __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+  }
+  __syncthreads();
+  __threadfence_system();
+}
+
+template <typename Tag>
+__global__ void __launch_bounds__(kArThreads) allreduce_two_shot_kernel(ArParams p) {
+  typedef uint16_t T;
+  const ArRegion L = ar_layout(p.max_bytes);
+  char *self = p.base[p.rank];
+  uint32_t *epoch_p = (uint32_t *)(self + L.epoch_off);
+  uint32_t *status = (uint32_t *)(self + L.status_off);
+  const uint32_t epoch = __hip_atomic_load(epoch_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const int parity = epoch & 1;
+  const int W = p.world;
+  // vectors of 8 elements; slice j = vectors [j*vs, (j+1)*vs), sub-chunk b = a contiguous vc-vector piece of it
+  const int64_t nvec = p.n >> 3;
+  const int64_t vs = nvec / W;             // host guarantees nvec % W == 0
+  const int64_t vc = (vs + kArBlocks - 1) / kArBlocks;
+  const int64_t c0 = (int64_t)blockIdx.x * vc, c1 = min(vs, c0 + vc);
+  const size_t stage_off = (size_t)parity * L.staging_bytes;
+
+  // 0. copy-in: sub-chunk b of every slice
+  const u32x4 *xin = (const u32x4 *)p.x;
+  u32x4 *mine = (u32x4 *)(self + stage_off);
+  for (int j = 0; j < W; ++j)
+    for (int64_t i = c0 + threadIdx.x; i < c1; i += kArThreads) mine[j * vs + i] = xin[j * vs + i];
+  peer_barrier(p, L, parity, 0, epoch, status);
+
+  // 2. reduce sub-chunk b of slice `rank` over all ranks, in rank order (all W loads in flight together)
+  for (int64_t i = c0 + threadIdx.x; i < c1; i += kArThreads) {
+    const uint32_t off = (uint32_t)(((int64_t)p.rank * vs + i) * 16);
+    u32x4 v[kMaxWorld];
+#pragma unroll
+    for (int q = 0; q < kMaxWorld; ++q)
+      if (q < W) v[q] = load_sys(make_rsrc(p.base[q] + stage_off, L.staging_bytes), off);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < kMaxWorld; ++q)
+      if (q < W) {
+        float f[8];
+        unpack8<Tag>(v[q], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += f[e];
+      }
+    mine[(int64_t)p.rank * vs + i] = pack8<Tag>(acc);
+  }
+  peer_barrier(p, L, parity, 1, epoch, status);
+
+  // 4. gather the reduced sub-chunk b of slice j from rank j
+  u32x4 *out = (u32x4 *)p.out;
+  for (int64_t i = c0 + threadIdx.x; i < c1; i += kArThreads) {
+    u32x4 v[kMaxWorld];
+#pragma unroll
+    for (int j = 0; j < kMaxWorld; ++j)
+      if (j < W) v[j] = load_sys(make_rsrc(p.base[j] + stage_off, L.staging_bytes), (uint32_t)(((int64_t)j * vs + i) * 16));
+#pragma unroll
+    for (int j = 0; j < kMaxWorld; ++j)
+      if (j < W) out[j * vs + i] = v[j];
+  }
+
+  // advance the call counter once every block of this rank is past its last flag use
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t *done = epoch_p + 1;
+    const uint32_t t = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (uint32_t)gridDim.x - 1) {
+      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(epoch_p, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t mv_ar_region_bytes(size_t max_bytes) { return ar_layout(max_bytes).total; }
+extern "C" int mv_ar_max_world(void) { return kMaxWorld; }
+
+extern "C" int mv_ar_alloc(size_t max_bytes, void **base_out) {
+  if (!base_out || max_bytes == 0) return MV_E_NULLPTR;
+  const size_t total = ar_layout(max_bytes).total;
+  void *p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, total, hipDeviceMallocUncached);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemset(p, 0, total);
+  if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
+  e = hipDeviceSynchronize();
+  if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
+  *base_out = p;
+  return MV_OK;
+}
+
+extern "C" int mv_ar_free(void *base) { return base ? mv_check_hip(hipFree(base)) : MV_OK; }
+
+extern "C" int mv_ar_ipc_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+extern "C" int mv_ar_ipc_export(void *base, void *handle_out) {
+  if (!base || !handle_out) return MV_E_NULLPTR;
+  return mv_check_hip(hipIpcGetMemHandle((hipIpcMemHandle_t *)handle_out, base));
+}
+
+extern "C" int mv_ar_ipc_open(const void *handle, void **ptr_out) {
+  if (!handle || !ptr_out) return MV_E_NULLPTR;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  return mv_check_hip(hipIpcOpenMemHandle(ptr_out, h, hipIpcMemLazyEnablePeerAccess));
+}
+
+extern "C" int mv_ar_ipc_close(void *ptr) { return ptr ? mv_check_hip(hipIpcCloseMemHandle(ptr)) : MV_OK; }
+
+// status word of the own region: 0 = every wait so far was satisfied.  Host call, synchronises the device.
+extern "C" int mv_ar_status(void *base, size_t max_bytes, uint32_t *status_out) {
+  if (!base || !status_out) return MV_E_NULLPTR;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return (int)e;
+  return mv_check_hip(hipMemcpy(status_out, (char *)base + ar_layout(max_bytes).status_off, sizeof(uint32_t),
+                                hipMemcpyDeviceToHost));
+}
+
+extern "C" int mv_ar_all_reduce(const void *x, void *out, int64_t n, void *const *bases, int rank, int world,
+                                size_t max_bytes, int dtype, void *stream) {
+  if (n == 0) return MV_OK;
+  if (!x || !out || !bases) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (world < 2 || world > kMaxWorld || rank < 0 || rank >= world) return MV_E_RANGE;
+  if (n < 0 || (n % (8 * world)) != 0 || (size_t)n * 2 > max_bytes) return MV_E_SHAPE;
+  if (!mv_aligned16(x) || !mv_aligned16(out)) return MV_E_ALIGN;
+  ArParams p;
+  for (int q = 0; q < kMaxWorld; ++q) p.base[q] = q < world ? (char *)bases[q] : nullptr;
+  for (int q = 0; q < world; ++q)
+    if (!p.base[q]) return MV_E_NULLPTR;
+  p.x = x;
+  p.out = out;
+  p.max_bytes = max_bytes;
+  p.n = n;
+  p.rank = rank;
+  p.world = world;
+  if (dtype == MV_BF16)
+    hipLaunchKernelGGL((allreduce_two_shot_kernel<bf16_tag>), dim3(kArBlocks), dim3(kArThreads), 0,
+                       (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((allreduce_two_shot_kernel<f16_tag>), dim3(kArBlocks), dim3(kArThreads), 0,
+                       (hipStream_t)stream, p);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}

@@ -1,0 +1,159 @@
+"""Small-message all-reduce over xGMI peer-to-peer loads (csrc/allreduce.hip) for the tensor-parallel
+decode step: the [tokens, hidden] sums after o_proj / down_proj and the embedding
+(minivllm/models/layers/linear.py:316-318, layers/embed_head.py:170-173 call ``dist.all_reduce``).
+
+Set-up is collective and conservative: every rank allocates one uncached region, the IPC handles are
+exchanged through the process group, and the kernel is then VALIDATED against the backend's own
+all-reduce on exact (integer-valued) data, several calls back to back.  Only if every rank reports
+success is the kernel used; any failure (allocation, IPC, a wait that gave up, a mismatch) leaves RCCL
+in charge.  ``MV_CUSTOM_AR=0`` disables it."""
+from __future__ import annotations
+
+import ctypes
+import logging
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import hip_ops
+
+logger = logging.getLogger(__name__)
+
+__all__ = ["CustomAllReduce", "maybe_create"]
+
+MAX_BYTES = 8 << 20           # largest message taken (256 tokens x 8192 x 2 B = 4 MiB for Qwen2-72B)
+_lib = hip_ops._lib
+
+
+def _all_ok(ok: bool, group) -> bool:
+    """Collective AND over the ranks (host side)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        flag = flag.cuda()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())
+
+
+class CustomAllReduce:
+    def __init__(self, rank: int, world: int, device: torch.device, group=None, max_bytes: int = MAX_BYTES) -> None:
+        self.rank, self.world, self.device, self.group = rank, world, device, group
+        self.max_bytes = int(max_bytes)
+        self.base = ctypes.c_void_p()
+        self.peers: list[int | None] = [None] * world
+        self.bases = (ctypes.c_void_p * 8)()
+        self.ready = False
+        self.calls = 0
+
+    # ------------------------------------------------------------------ collective set-up
+    def setup(self) -> bool:
+        g = self.group
+        ok = True
+        handle = b""
+        try:
+            if self.world > int(_lib.mv_ar_max_world()):
+                raise RuntimeError(f"world size {self.world} not supported")
+            hip_ops._check(_lib.mv_ar_alloc(self.max_bytes, ctypes.byref(self.base)), "mv_ar_alloc")
+            buf = ctypes.create_string_buffer(int(_lib.mv_ar_ipc_handle_bytes()))
+            hip_ops._check(_lib.mv_ar_ipc_export(self.base, buf), "mv_ar_ipc_export")
+            handle = buf.raw
+        except Exception as e:  # noqa: BLE001 - any local failure only disables the fast path
+            logger.warning("custom all-reduce: allocation/export failed on rank %d: %s", self.rank, e)
+            ok = False
+        if not _all_ok(ok, g):
+            return self._give_up()
+        handles: list = [None] * self.world
+        dist.all_gather_object(handles, handle, group=g)
+        try:
+            for q, h in enumerate(handles):
+                if q == self.rank:
+                    self.bases[q] = self.base.value
+                    continue
+                ptr = ctypes.c_void_p()
+                hip_ops._check(_lib.mv_ar_ipc_open(ctypes.create_string_buffer(h, len(h)), ctypes.byref(ptr)),
+                               "mv_ar_ipc_open")
+                self.peers[q] = ptr.value
+                self.bases[q] = ptr.value
+        except Exception as e:  # noqa: BLE001
+            logger.warning("custom all-reduce: IPC open failed on rank %d: %s", self.rank, e)
+            ok = False
+        if not _all_ok(ok, g):
+            return self._give_up()
+        try:
+            ok = self._validate()
+        except Exception as e:  # noqa: BLE001
+            logger.warning("custom all-reduce: validation raised on rank %d: %s", self.rank, e)
+            ok = False
+        if not _all_ok(ok, g):
+            return self._give_up()
+        self.ready = True
+        logger.info("custom all-reduce enabled (rank %d of %d, messages up to %d KiB)", self.rank, self.world,
+                    self.max_bytes >> 10)
+        return True
+
+    def _give_up(self) -> bool:
+        logger.warning("custom all-reduce disabled on rank %d: the backend's all-reduce stays in charge", self.rank)
+        self.close()
+        return False
+
+    def _validate(self) -> bool:
+        """Exact comparison with the backend's all-reduce: integer-valued data sums exactly in bf16/f16 in any
+        order.  Several sizes, several calls in a row without a host sync in between (flag parity reuse)."""
+        gen = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+        good = True
+        for dtype in (torch.bfloat16, torch.float16):
+            for n in (8 * self.world, 1024 * self.world, 256 * 2048, 256 * 3584, self.max_bytes // 2):
+                n -= n % (8 * self.world)
+                pairs = []
+                for _ in range(5):
+                    x = torch.randint(-6, 7, (n,), generator=gen).to(dtype).to(self.device)
+                    want = x.clone()
+                    got = self._launch(x, torch.empty_like(x))
+                    inplace = self._launch(x.clone(), None)
+                    pairs.append((want, got, inplace))
+                for want, got, inplace in pairs:
+                    dist.all_reduce(want, group=self.group)
+                    good = good and torch.equal(got, want) and torch.equal(inplace, want)
+        return good and self.status() == 0
+
+    # ------------------------------------------------------------------ use
+    def accepts(self, x: torch.Tensor) -> bool:
+        return (self.ready and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous()
+                and 0 < x.numel() * 2 <= self.max_bytes and x.numel() % (8 * self.world) == 0
+                and x.data_ptr() % 16 == 0)
+
+    def _launch(self, x: torch.Tensor, out: torch.Tensor | None) -> torch.Tensor:
+        out = x if out is None else out
+        hip_ops._check(_lib.mv_ar_all_reduce(x.data_ptr(), out.data_ptr(), x.numel(), self.bases, self.rank,
+                                             self.world, self.max_bytes, hip_ops._dt(x), hip_ops._stream()),
+                       "mv_ar_all_reduce")
+        self.calls += 1
+        return out
+
+    def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
+        """In-place SUM over the ranks (``accepts(x)`` must hold)."""
+        return self._launch(x, None)
+
+    def status(self) -> int:
+        """0 while every peer wait of every call so far was satisfied (host call: synchronises the device)."""
+        st = ctypes.c_uint32(0)
+        hip_ops._check(_lib.mv_ar_status(self.base, self.max_bytes, ctypes.byref(st)), "mv_ar_status")
+        return int(st.value)
+
+    def close(self) -> None:
+        self.ready = False
+        for q, ptr in enumerate(self.peers):
+            if ptr:
+                _lib.mv_ar_ipc_close(ctypes.c_void_p(ptr))
+                self.peers[q] = None
+        if self.base:
+            _lib.mv_ar_free(self.base)
+            self.base = ctypes.c_void_p()
+
+
+def maybe_create(rank: int, world: int, device: torch.device, group=None) -> CustomAllReduce | None:
+    """Collective: every rank of ``group`` must call it.  Returns the ready object, or None."""
+    if world < 2 or os.environ.get("MV_CUSTOM_AR", "1") == "0" or device.type != "cuda":
+        return None
+    ar = CustomAllReduce(rank, world, device, group)
+    return ar if ar.setup() else None

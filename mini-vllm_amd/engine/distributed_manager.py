@@ -41,6 +41,14 @@ class DistributedManager:
             self._validate_setup()
         parallel_state.init_tensor_parallel(self.rank if self.is_distributed else 0,
                                             self.world_size if self.is_distributed else 1)
+        if self.is_distributed and torch.cuda.is_available():
+            from ..custom_allreduce import maybe_create
+
+            # the device this rank will run on (ModelManager._setup_device makes the same choice)
+            local = int(os.environ.get("LOCAL_RANK", self.rank)) % torch.cuda.device_count()
+            torch.cuda.set_device(local)
+            parallel_state.set_custom_all_reduce(
+                maybe_create(self.rank, self.world_size, torch.device("cuda", local)))
         self._initialized = True
 
     def _setup_distributed_backend(self) -> None:

@@ -51,6 +51,16 @@ _SIGNATURES = {
                                   c_int, c_int, c_void_p]),
     "mv_gate_up_silu_small_m": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                         c_int, c_void_p]),
+    "mv_ar_region_bytes": (c_size_t, [c_size_t]),
+    "mv_ar_max_world": (c_int, []),
+    "mv_ar_alloc": (c_int, [c_size_t, c_void_p]),
+    "mv_ar_free": (c_int, [c_void_p]),
+    "mv_ar_ipc_handle_bytes": (c_int, []),
+    "mv_ar_ipc_export": (c_int, [c_void_p, c_void_p]),
+    "mv_ar_ipc_open": (c_int, [c_void_p, c_void_p]),
+    "mv_ar_ipc_close": (c_int, [c_void_p]),
+    "mv_ar_status": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "mv_ar_all_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_size_t, c_int, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

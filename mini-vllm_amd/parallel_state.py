@@ -7,17 +7,25 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-_state = {"rank": 0, "size": 1, "group": None}
+_state = {"rank": 0, "size": 1, "group": None, "custom_ar": None}
 
 
 def init_tensor_parallel(rank: int, size: int, group=None) -> None:
     if size < 1 or not 0 <= rank < size:
         raise ValueError(f"invalid tensor-parallel rank/size {rank}/{size}")
-    _state.update(rank=rank, size=size, group=group)
+    _state.update(rank=rank, size=size, group=group, custom_ar=None)
+
+
+def set_custom_all_reduce(ar) -> None:
+    """The validated peer-to-peer kernel (custom_allreduce.CustomAllReduce) for small 16-bit messages."""
+    _state["custom_ar"] = ar
 
 
 def reset_tensor_parallel() -> None:
-    _state.update(rank=0, size=1, group=None)
+    ar = _state.get("custom_ar")
+    if ar is not None:
+        ar.close()
+    _state.update(rank=0, size=1, group=None, custom_ar=None)
 
 
 def get_tensor_parallel_rank() -> int:
@@ -33,8 +41,12 @@ def get_tensor_parallel_group():
 
 
 def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
-    """In-place SUM over the TP group (C1/C2: after o_proj, down_proj and the embedding)."""
+    """In-place SUM over the TP group (C1/C2: after o_proj, down_proj and the embedding): decode-sized
+    16-bit messages on the peer-to-peer kernel when it passed its validation, everything else on RCCL."""
     if _state["size"] > 1:
+        ar = _state["custom_ar"]
+        if ar is not None and ar.accepts(x):
+            return ar.all_reduce(x)
         dist.all_reduce(x, group=_state["group"])
     return x
 

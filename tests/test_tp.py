@@ -204,3 +204,48 @@ def test_tp2_logits_match_reference_on_one_gpu(golden_dir, tmp_path):
         r = json.loads(open(out + f".{rank}").read())
         assert max(r["errs"]) <= 2e-4 * r["scale"], r
         assert r["greedy_ok"], r
+
+
+# ---------------------------------------------------------------------------------- GPU, peer-to-peer all-reduce
+def _custom_ar_worker(rank, world, port, out_path):
+    _init(rank, world, port)
+    torch.cuda.set_device(0)                          # every rank on the one GPU of the box: IPC within the device
+    from minivllm_amd import parallel_state
+    from minivllm_amd.custom_allreduce import maybe_create
+
+    ar = maybe_create(rank, world, torch.device("cuda", 0))
+    ok = ar is not None                                # set-up includes the exact validation against gloo
+    errs = []
+    if ok:
+        parallel_state.set_custom_all_reduce(ar)
+        g = torch.Generator().manual_seed(100 + rank)
+        for shape, dtype in (((256, 2048), torch.bfloat16), ((8, 3584), torch.float16), ((1, 1024), torch.bfloat16),
+                             ((3, 8 * world), torch.bfloat16)):
+            x = torch.randn(shape, generator=g).to(dtype).cuda()
+            want = x.float().clone()
+            dist.all_reduce(want)                      # fp32 sum of the 16-bit inputs (gloo)
+            for _ in range(3):                         # back-to-back calls reuse both flag parities
+                got = parallel_state.tp_all_reduce(x.clone())
+            # fp32 accumulation, one rounding: within half an ulp of the exact sum
+            eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+            errs.append(bool(((got.float() - want).abs() <= eps * want.abs() + 1e-6).all()))
+        calls = ar.calls
+        big = torch.zeros(4 << 20, dtype=torch.bfloat16, device="cuda")      # 8 MiB + : above the limit -> backend
+        odd = torch.zeros(8 * world + 8, dtype=torch.bfloat16, device="cuda")[:-8] if world > 1 else None
+        f32 = torch.zeros(1024, device="cuda")
+        parallel_state.tp_all_reduce(big[: (4 << 20) + 0])
+        parallel_state.tp_all_reduce(f32)
+        ok = ok and all(errs) and ar.status() == 0 and not ar.accepts(f32) and ar.calls == calls + (1 if ar.accepts(big) else 0)
+    dist.barrier()
+    open(out_path + f".{rank}", "w").write("ok" if ok else f"bad {errs}")
+    parallel_state.reset_tensor_parallel()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_custom_all_reduce_matches_backend(tmp_path, world):
+    out = str(tmp_path / "res")
+    mp.spawn(_custom_ar_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for rank in range(world):
+        assert open(out + f".{rank}").read() == "ok"
