@@ -249,3 +249,46 @@ def test_custom_all_reduce_matches_backend(tmp_path, world):
     mp.spawn(_custom_ar_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     for rank in range(world):
         assert open(out + f".{rank}").read() == "ok"
+
+
+# ---------------------------------------------------------------------------------- GPU, LLM(tensor_parallel_size=2)
+@pytest.mark.gpu
+def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
+    """The user path: ``LLM(Config(dir, tensor_parallel_size=2))`` from ONE process spawns rank 1, both ranks
+    run the same scheduler (SPMD), requests travel over the control group; greedy output equals TP=1.
+    Both ranks share the box's single GPU (gloo for the collectives, the peer-to-peer kernel for the bf16
+    all-reduces), so this is a functional test of the multi-process flow, not of xGMI."""
+    from safetensors.torch import save_file
+
+    from minivllm_amd import LLM, Config, SamplingParams
+
+    z = np.load(os.path.join(golden_dir, "e2e_qwen3.npz"))
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    (d / "config.json").write_text(bytes(z["config_json"]).decode())
+    weights = {k[2:]: torch.from_numpy(z[k].view(np.int16).copy()).view(torch.bfloat16).contiguous()
+               for k in z.files if k.startswith("w:")}
+    save_file(weights, str(d / "model.safetensors"))
+    lens, flat = z["prompt_lens"].tolist(), z["prompts"].tolist()
+    prompts, o = [], 0
+    for n in lens:
+        prompts.append(flat[o:o + n]); o += n
+    sp = SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True)
+    kw = dict(max_model_len=512, max_num_batched_tokens=1024, max_num_seqs=8, num_kvcache_blocks=24,
+              enforce_eager=True)
+
+    def run(tp, dtype):
+        llm = LLM(Config(str(d), dtype=dtype, tensor_parallel_size=tp, **kw))
+        try:
+            return [o_["token_ids"] for o_ in llm.generate(prompts, sp, use_tqdm=False)]
+        finally:
+            llm.exit()
+
+    monkeypatch.setenv("MINIVLLM_TP_BACKEND", "gloo")
+    # fp32: TP only reorders fp32 sums (1e-6 relative) -> identical greedy tokens
+    assert run(2, "float32") == run(1, "float32")
+    # bf16 (all-reduces on the peer-to-peer kernel): same lengths, and the first tokens agree (later ones may
+    # legitimately diverge after a near-tie, as between any two bf16 summation orders)
+    a, b = run(2, "bfloat16"), run(1, "bfloat16")
+    assert [len(t) for t in a] == [len(t) for t in b] == [12] * len(prompts)
+    assert sum(x[0] == y[0] for x, y in zip(a, b)) >= len(prompts) - 1
