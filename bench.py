@@ -233,7 +233,7 @@ def main():
         assert len(engine.scheduler.running) == args.batch, "a sequence finished inside the timed region"
         roof = decode_roofline(engine, args)
         ex = engine.model_runner.inference_executor
-        graphs = bool(ex.graphs)
+        graphs = bool(ex.graphs or ex.greedy_graphs)
         allreduce = None
         if args.gpus > 1:
             from minivllm_amd import parallel_state

@@ -217,6 +217,19 @@ int mv_ar_status(void *base, size_t max_bytes, uint32_t *status_out);
 int mv_ar_all_reduce(const void *x, void *out, int64_t n, void *const *bases,
                      int rank, int world, size_t max_bytes, int dtype, void *stream);
 
+/* f2 — greedy decoding under tensor parallelism without the logit all-gather (replaces, for all-greedy
+ * batches, the gather of ParallelLMHead.forward, minivllm/models/layers/embed_head.py:219-229, + argmax).
+ * mv_greedy_pack: buf [world][rows_padded][4] (16-bit dtype) <- zeros, except slot [rank][r] =
+ *   (logits_local[r][local_tokens[r]], three 8-bit pieces of the GLOBAL index rank*vocab_per_rank + token),
+ *   all exactly representable; local_tokens = shard-local argmax (mv_sample at temperature 0).
+ * After an exact sum all-reduce of buf (mv_ar_all_reduce: x + 0 = x), mv_greedy_merge writes per row the
+ * global index of the largest value, lowest index on ties.  world * vocab_per_rank <= 2^24. */
+int mv_greedy_pack(const void *logits_local, int64_t ld, const int64_t *local_tokens,
+                   int rank, int world, int64_t vocab_per_rank, int rows,
+                   int rows_padded, void *buf, int dtype, void *stream);
+int mv_greedy_merge(const void *buf, int world, int rows, int rows_padded,
+                    int64_t *tokens, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,7 +169,87 @@ __global__ void __launch_bounds__(kArThreads) allreduce_two_shot_kernel(ArParams
   }
 }
 
+// f2: greedy decoding under tensor parallelism without gathering the logits.  Every rank packs,
+// per row, the maximum of its vocab shard and the global index of that maximum into four 16-bit floats that
+// are EXACT in bf16/f16 (the logit itself; three 8-bit pieces of the index) at slot [rank] of a zeroed
+// [world][rows][4] buffer; the all-reduce above (sum with zeros = gather, exact) then hands every rank all
+// candidates, and the merge keeps the largest value, lowest global index on ties — argmax of the full row.
+template <typename Tag>
+__global__ void greedy_pack_kernel(const uint16_t *logits, int64_t ld, const int64_t *local_tokens, int rank, int world,
+                                   int64_t vocab_per_rank, int rows, int rows_padded, uint16_t *buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over world * rows_padded
+  if (i >= world * rows_padded) return;
+  const int q = i / rows_padded, r = i - q * rows_padded;
+  u32x2 w = {0u, 0u};
+  if (q == rank && r < rows) {
+    const int64_t t = local_tokens[r], g = t + (int64_t)rank * vocab_per_rank;
+    const uint32_t val = logits[(int64_t)r * ld + t];
+    w[0] = val | ((uint32_t)elem<Tag>::st((float)((g >> 16) & 255)) << 16);
+    w[1] = (uint32_t)elem<Tag>::st((float)((g >> 8) & 255)) | ((uint32_t)elem<Tag>::st((float)(g & 255)) << 16);
+  }
+  *(u32x2 *)(buf + (int64_t)i * 4) = w;
+}
+
+template <typename Tag>
+__global__ void greedy_merge_kernel(const uint16_t *buf, int world, int rows, int rows_padded, int64_t *tokens) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float best = -INFINITY;
+  int64_t best_idx = INT64_MAX;
+  for (int q = 0; q < world; ++q) {
+    const u32x2 w = *(const u32x2 *)(buf + ((int64_t)q * rows_padded + r) * 4);
+    const float v = elem<Tag>::ld((uint16_t)(w[0] & 0xffffu));
+    const int64_t g = ((int64_t)elem<Tag>::ld((uint16_t)(w[0] >> 16)) << 16) |
+                      ((int64_t)elem<Tag>::ld((uint16_t)(w[1] & 0xffffu)) << 8) |
+                      (int64_t)elem<Tag>::ld((uint16_t)(w[1] >> 16));
+    if (v > best || (v == best && g < best_idx) || best_idx == INT64_MAX) {
+      best = v;
+      best_idx = g;
+    }
+  }
+  tokens[r] = best_idx;
+}
+
 }  // namespace
+
+extern "C" int mv_greedy_pack(const void *logits_local, int64_t ld, const int64_t *local_tokens, int rank, int world,
+                              int64_t vocab_per_rank, int rows, int rows_padded, void *buf, int dtype,
+                              void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!logits_local || !local_tokens || !buf) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (rows < 0 || rows_padded < rows || world < 1 || rank < 0 || rank >= world ||
+      vocab_per_rank * world > (1 << 24))
+    return MV_E_SHAPE;
+  if (((uintptr_t)buf) & 7u) return MV_E_ALIGN;
+  const int n = world * rows_padded;
+  if (dtype == MV_BF16)
+    hipLaunchKernelGGL((greedy_pack_kernel<bf16_tag>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)logits_local, ld, local_tokens, rank, world, vocab_per_rank, rows,
+                       rows_padded, (uint16_t *)buf);
+  else
+    hipLaunchKernelGGL((greedy_pack_kernel<f16_tag>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)logits_local, ld, local_tokens, rank, world, vocab_per_rank, rows,
+                       rows_padded, (uint16_t *)buf);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_greedy_merge(const void *buf, int world, int rows, int rows_padded, int64_t *tokens, int dtype,
+                               void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!buf || !tokens) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (rows < 0 || rows_padded < rows || world < 1) return MV_E_SHAPE;
+  if (dtype == MV_BF16)
+    hipLaunchKernelGGL((greedy_merge_kernel<bf16_tag>), dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)buf, world, rows, rows_padded, tokens);
+  else
+    hipLaunchKernelGGL((greedy_merge_kernel<f16_tag>), dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)buf, world, rows, rows_padded, tokens);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
 
 extern "C" size_t mv_ar_region_bytes(size_t max_bytes) { return ar_layout(max_bytes).total; }
 extern "C" int mv_ar_max_world(void) { return kMaxWorld; }

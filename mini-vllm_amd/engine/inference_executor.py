@@ -21,7 +21,7 @@ import torch
 
 from ..config import Config
 from ..layers.sampler import Sampler
-from ..parallel_state import get_tensor_parallel_world_size, tp_merge_greedy
+from ..parallel_state import get_tensor_parallel_world_size, decode_step_is_native, tp_greedy_tokens
 from ..utils.context import reset_context, set_context
 from .. import hip_ops
 from .input_builder import BatchInputs, InputBuilder
@@ -196,7 +196,7 @@ class InferenceExecutor:
                 logits = self.model.compute_logits(self.model(ids, pos), gather=not greedy)
                 tokens = self._sample_tokens(logits, sequences, tp_greedy=greedy)
             else:
-                bs = self._graph_bucket(len(sequences))
+                bs = self._graph_bucket(sequences)
                 inp = self.builder.decode(sequences, pad_to=bs)
                 if bs is not None and inp.packed:
                     logits, tokens = self._replay_graph(bs, inp, sequences)
@@ -268,8 +268,7 @@ class InferenceExecutor:
         """Tokens of an all-greedy batch from this rank's vocab shard (temperature 0 rows: the sampler
         kernel returns the lowest-index argmax of the shard)."""
         local = self.sampler(logits_local, temperatures=t, top_ks=k, top_ps=p, min_ps=m)
-        vals = logits_local.gather(1, local.unsqueeze(1)).squeeze(1)
-        return tp_merge_greedy(local, vals, logits_local.shape[1])
+        return tp_greedy_tokens(logits_local, local)
 
     def _sample_tokens(self, logits, sequences, tp_greedy: bool = False) -> list[int]:
         if self.sampler is None:
@@ -294,22 +293,30 @@ class InferenceExecutor:
         self.total_tokens_generated += len(sequences)
 
     # ------------------------------------------------------------------ hipGraph decode
-    def _graph_bucket(self, batch_size: int) -> int | None:
-        if self.enforce_eager or not self.graphs:
+    def _graph_bucket(self, sequences) -> int | None:
+        """Smallest captured bucket that holds the batch, in the graph family the batch decodes with."""
+        if self.enforce_eager:
             return None
-        return next((bs for bs in self.graph_bs if bs >= batch_size and bs in self.graphs), None)
+        family = self.greedy_graphs if self.greedy_graphs and self._tp_greedy(sequences) else self.graphs
+        return next((bs for bs in self.graph_bs if bs >= len(sequences) and bs in family), None)
 
     def capture_device_graphs(self, max_batch_size: int) -> None:
         """Capture one hipGraph per decode batch-size bucket (largest first, shared pool)."""
         if self.enforce_eager:
             return
-        if get_tensor_parallel_world_size() > 1:
+        general_ok = True
+        if self.tp_size > 1:
             import torch.distributed as dist
 
             if dist.get_backend() != "nccl":
-                # only RCCL collectives can be captured; a failed capture cannot be recovered from
-                logger.warning("tensor-parallel backend %s is not capturable: decoding eagerly", dist.get_backend())
-                return
+                # only RCCL collectives can be captured (and a failed capture cannot be recovered from): the
+                # gathered-logits graphs are skipped; the all-greedy graphs contain no backend collective when
+                # the peer-to-peer all-reduce is up, and are captured
+                general_ok = False
+                hf_ = self.config.hf_config
+                if not decode_step_is_native(self.dtype, hf_.hidden_size, hf_.vocab_size):
+                    logger.warning("tensor-parallel backend %s is not capturable: decoding eagerly", dist.get_backend())
+                    return
         self.graph_bs = graph_batch_sizes(min(max_batch_size, self.config.max_num_seqs))
         max_bs = self.graph_bs[-1]
         hidden = self.config.hf_config.hidden_size
@@ -333,10 +340,19 @@ class InferenceExecutor:
                               for bs in self.graph_bs), dev)
         self.sampler.offset_dev = gv["rng_offset"]
         try:
-            for bs in reversed(self.graph_bs):
-                self._capture_one(bs, greedy=False)
-                if self.tp_size > 1:
+            if self.tp_size > 1:   # first the family without a backend collective inside
+                for bs in reversed(self.graph_bs):
                     self._capture_one(bs, greedy=True)
+            try:
+                for bs in reversed(self.graph_bs):
+                    if general_ok:
+                        self._capture_one(bs, greedy=False)
+            except Exception as e:
+                if not self.greedy_graphs:
+                    raise
+                logger.warning("Failed to capture the gathered-logits graphs (sampled batches decode eagerly): %s", e)
+                self.graphs.clear()
+                self._recover_from_failed_capture()
             logger.info("Captured %d decode graphs (batch sizes %s..%d)", len(self.graphs) + len(self.greedy_graphs),
                         self.graph_bs[:4], self.graph_bs[-1])
         except Exception as e:  # fall back to eager, loudly
@@ -345,14 +361,17 @@ class InferenceExecutor:
             self.greedy_graphs.clear()
             self.graph_pool = None
             self.sampler.offset_dev = None
-            reset_context()
-            # a failed capture leaves torch's side capture stream current (torch.cuda.graph.__exit__
-            # raises in capture_end before restoring it): go back to the default stream
-            torch.cuda.set_stream(torch.cuda.default_stream(self.device))
-            try:
-                torch.cuda.synchronize(self.device)
-            except Exception:  # the invalidated capture reports once more; the device itself is fine
-                pass
+            self._recover_from_failed_capture()
+
+    def _recover_from_failed_capture(self) -> None:
+        reset_context()
+        # a failed capture leaves torch's side capture stream current (torch.cuda.graph.__exit__
+        # raises in capture_end before restoring it): go back to the default stream
+        torch.cuda.set_stream(torch.cuda.default_stream(self.device))
+        try:
+            torch.cuda.synchronize(self.device)
+        except Exception:  # the invalidated capture reports once more; the device itself is fine
+            pass
 
     def _graph_forward(self, bs: int, greedy: bool = False):
         gv = self.graph_vars
@@ -365,7 +384,7 @@ class InferenceExecutor:
             out.copy_(self.model.compute_logits(hidden, gather=False))
             local = hip_ops.sample(out, d[0, :bs], self._dev_samp_i64[:bs], d[1, :bs], d[2, :bs],
                                    seed=self.sampler.seed, offset=0, offset_dev=gv["rng_offset"])
-            toks = tp_merge_greedy(local, out.gather(1, local.unsqueeze(1)).squeeze(1), out.shape[1])
+            toks = tp_greedy_tokens(out, local)
         else:
             out = gv["logits"][:bs]
             out.copy_(self.model.compute_logits(hidden))
@@ -407,7 +426,7 @@ class InferenceExecutor:
         with identical values or that belong to finished sequences."""
         b = inp.num_seqs
         gv = self.graph_vars
-        greedy = bs in self.greedy_graphs and self._tp_greedy(sequences)
+        greedy = bool(self.greedy_graphs) and self._tp_greedy(sequences)
         graph = self.greedy_graphs[bs] if greedy else self.graphs[bs]
         spec, self._spec = self._spec, None
         hit = False

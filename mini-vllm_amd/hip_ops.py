@@ -61,6 +61,9 @@ _SIGNATURES = {
     "mv_ar_ipc_close": (c_int, [c_void_p]),
     "mv_ar_status": (c_int, [c_void_p, c_size_t, c_void_p]),
     "mv_ar_all_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_size_t, c_int, c_void_p]),
+    "mv_greedy_pack": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int,
+                               c_void_p]),
+    "mv_greedy_merge": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -373,6 +376,26 @@ def gate_up_silu_small_m(x, weight):
                                         out.stride(0), x2.shape[0], n, k, _dt(x), _stream()),
            "mv_gate_up_silu_small_m")
     return out.view(*x.shape[:-1], n)
+
+
+# ---------------------------------------------------------------- f2
+def greedy_pack(logits_local, local_tokens, rank: int, world: int, rows_padded: int):
+    """-> buf [world, rows_padded, 4] in the logits' dtype (see mv_greedy_pack)."""
+    _need_cuda(logits_local, local_tokens)
+    rows, vpr = logits_local.shape
+    buf = torch.empty((world, rows_padded, 4), dtype=logits_local.dtype, device=logits_local.device)
+    _check(_lib.mv_greedy_pack(logits_local.data_ptr(), logits_local.stride(0), local_tokens.data_ptr(), rank, world,
+                               vpr, rows, rows_padded, buf.data_ptr(), _dt(logits_local), _stream()),
+           "mv_greedy_pack")
+    return buf
+
+
+def greedy_merge(buf, rows: int):
+    world, rows_padded, _ = buf.shape
+    out = torch.empty((rows,), dtype=torch.int64, device=buf.device)
+    _check(_lib.mv_greedy_merge(buf.data_ptr(), world, rows, rows_padded, out.data_ptr(), _dt(buf), _stream()),
+           "mv_greedy_merge")
+    return out
 
 
 # ---------------------------------------------------------------- a2 (device side)

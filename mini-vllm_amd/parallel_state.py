@@ -91,6 +91,33 @@ def tp_merge_greedy(local_tokens: torch.Tensor, local_values: torch.Tensor, voca
     return torch.where(vals == best, idx, torch.full_like(idx, float("inf"))).min(dim=0).values.long()
 
 
+def tp_greedy_tokens(logits_local: torch.Tensor, local_tokens: torch.Tensor) -> torch.Tensor:
+    """Tokens of an all-greedy batch from every rank's shard-local argmax.  With the peer-to-peer all-reduce
+    available the exchange is three launches of this library and no backend collective (the whole decode step
+    then captures into a graph without RCCL inside); otherwise ``tp_merge_greedy`` over the backend."""
+    n, vpr = logits_local.shape
+    ar, world = _state["custom_ar"], _state["size"]
+    if (ar is not None and logits_local.dtype in (torch.bfloat16, torch.float16) and world * vpr <= 1 << 24):
+        from . import hip_ops
+
+        buf = hip_ops.greedy_pack(logits_local, local_tokens, _state["rank"], world, n + (n & 1))
+        flat = buf.view(-1)
+        if ar.accepts(flat):
+            ar.all_reduce(flat)                      # sum with zeros = exact gather
+            return hip_ops.greedy_merge(buf, n)
+    vals = logits_local.gather(1, local_tokens.unsqueeze(1)).squeeze(1)
+    return tp_merge_greedy(local_tokens, vals, vpr)
+
+
+def decode_step_is_native(dtype: torch.dtype, hidden_size: int, vocab_size: int) -> bool:
+    """True when an all-greedy decode step of a model with these dimensions needs no backend collective: every
+    all-reduce and the greedy exchange run on this library's peer-to-peer kernel (-> the step captures into a
+    graph whatever the backend is)."""
+    ar, world = _state["custom_ar"], _state["size"]
+    return (ar is not None and ar.ready and dtype in (torch.bfloat16, torch.float16)
+            and hidden_size % (8 * world) == 0 and vocab_size <= 1 << 24)
+
+
 def divide(numerator: int, denominator: int) -> int:
     if numerator % denominator != 0:
         raise ValueError(f"{numerator} is not divisible by {denominator}")

@@ -475,3 +475,30 @@ def test_linear_small_m_argument_errors(H):
             H.linear_small_m(bad_x, bad_w)
         assert not H.linear_small_m_ok(bad_x, bad_w)
     assert H.linear_small_m_ok(x, w)
+
+
+# ------------------------------------------------------------------ f2
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_greedy_pack_merge_equals_argmax_of_gathered_row(H, dtype):
+    """Two vocab shards packed by 'rank 0' and 'rank 1', summed (what the all-reduce does: x + 0), merged:
+    the argmax of the concatenated row, lowest index on ties, indices above 2^16 included."""
+    world, rows, vpr = 2, 5, 75968
+    full = _randn(rows, world * vpr, dtype=dtype, seed=9).to(DEV)
+    full[1, 70000], full[1, 140000] = 9.0, 9.0          # tie across shards -> 70000
+    full[2, 151000], full[2, 151900] = 8.0, 8.0         # tie inside shard 1 -> 151000
+    full[3] = 0.5                                        # everything ties -> 0
+    full[4, 151935] = 11.0                               # last entry
+    zeros, ones = torch.zeros(rows, device=DEV), torch.ones(rows, device=DEV)
+    nok = torch.full((rows,), -1, dtype=torch.int64, device=DEV)
+    bufs = []
+    for rank in range(world):
+        shard = full[:, rank * vpr:(rank + 1) * vpr]    # a column block: row-strided view
+        local = H.sample(shard.contiguous(), zeros, nok, ones, zeros, seed=0)
+        bufs.append(H.greedy_pack(shard, local, rank, world, rows + 1))
+        assert bufs[-1].shape == (world, rows + 1, 4) and (bufs[-1][1 - rank] == 0).all()
+    summed = (bufs[0].float() + bufs[1].float()).to(dtype)
+    assert torch.equal(summed[0], bufs[0][0]) and torch.equal(summed[1], bufs[1][1])   # exact
+    got = H.greedy_merge(summed, rows)
+    want = torch.stack([torch.nonzero(r == r.max())[0, 0] for r in full.float()])
+    assert torch.equal(got, want), (got, want)
+    assert got.tolist()[1:] == [70000, 151000, 0, 151935]

@@ -277,18 +277,26 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
     kw = dict(max_model_len=512, max_num_batched_tokens=1024, max_num_seqs=8, num_kvcache_blocks=24,
               enforce_eager=True)
 
-    def run(tp, dtype):
-        llm = LLM(Config(str(d), dtype=dtype, tensor_parallel_size=tp, **kw))
+    def run(tp, dtype, eager=True):
+        llm = LLM(Config(str(d), dtype=dtype, tensor_parallel_size=tp, **{**kw, "enforce_eager": eager}))
         try:
-            return [o_["token_ids"] for o_ in llm.generate(prompts, sp, use_tqdm=False)]
+            ex = llm.model_runner.inference_executor
+            out = [o_["token_ids"] for o_ in llm.generate(prompts, sp, use_tqdm=False)]
+            return out, bool(ex.greedy_graphs), ex.spec_hits
         finally:
             llm.exit()
 
     monkeypatch.setenv("MINIVLLM_TP_BACKEND", "gloo")
     # fp32: TP only reorders fp32 sums (1e-6 relative) -> identical greedy tokens
-    assert run(2, "float32") == run(1, "float32")
+    assert run(2, "float32")[0] == run(1, "float32")[0]
     # bf16 (all-reduces on the peer-to-peer kernel): same lengths, and the first tokens agree (later ones may
     # legitimately diverge after a near-tie, as between any two bf16 summation orders)
-    a, b = run(2, "bfloat16"), run(1, "bfloat16")
+    (a, _, _), (b, _, _) = run(2, "bfloat16"), run(1, "bfloat16")
     assert [len(t) for t in a] == [len(t) for t in b] == [12] * len(prompts)
     assert sum(x[0] == y[0] for x, y in zip(a, b)) >= len(prompts) - 1
+    # hipGraph decode under TP: the all-greedy step has no backend collective inside (peer-to-peer all-reduce,
+    # packed argmax exchange), is captured even with gloo ranks, replays speculatively, and reproduces the
+    # eager TP=2 tokens bit for bit; fp32 models (backend all-reduce) are not captured with gloo
+    g, captured, spec_hits = run(2, "bfloat16", eager=False)
+    assert captured and spec_hits > 0 and g == a
+    assert not run(2, "float32", eager=False)[1]
