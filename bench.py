@@ -238,7 +238,7 @@ def main():
         if args.gpus > 1:
             from minivllm_amd import parallel_state
 
-            ar = parallel_state._state.get("custom_ar")
+            ar = parallel_state.get_custom_all_reduce()
             allreduce = "rccl" if ar is None else (
                 f"p2p two-shot kernel (validated against the backend at start-up, {ar.calls} calls)"
                 if ar.status() == 0 else "p2p two-shot kernel: A PEER WAIT TIMED OUT, RESULT INVALID")

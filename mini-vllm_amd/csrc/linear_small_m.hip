@@ -176,7 +176,11 @@ int launch(const LinearParams &p, int rpw, int mt, dim3 grid, dim3 block, size_t
   return launch_mt_<Tag, 1, GATED>(p, mt, grid, block, lds, stream);
 }
 
+// MV_LINEAR_RPW / MV_LINEAR_WAVES override the launch shape, for tools/bench_linear.py --sweep only: they are
+// looked at per call (the sweep changes them between calls) iff MV_LINEAR_TUNE was set when the library loaded
 int env_int(const char *name) {
+  static const bool tuning = getenv("MV_LINEAR_TUNE") != nullptr;
+  if (!tuning) return 0;
   const char *e = getenv(name);
   return e ? atoi(e) : 0;
 }

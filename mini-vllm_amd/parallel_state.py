@@ -21,6 +21,10 @@ def set_custom_all_reduce(ar) -> None:
     _state["custom_ar"] = ar
 
 
+def get_custom_all_reduce():
+    return _state["custom_ar"]
+
+
 def reset_tensor_parallel() -> None:
     ar = _state.get("custom_ar")
     if ar is not None:

@@ -9,6 +9,9 @@ import argparse
 import os
 import sys
 
+if "--sweep" in sys.argv:
+    os.environ["MV_LINEAR_TUNE"] = "1"   # before libmvhip.so is loaded: lets the launch-shape overrides through
+
 import torch
 import torch.nn.functional as F
 
