@@ -52,11 +52,13 @@ __global__ void rmsnorm_kernel(const typename elem<Tag>::T *__restrict__ x, int6
   const int nvec = cols / VEC;
   const typename elem<Tag>::T *xr = x + (int64_t)row * x_stride;
   float vals[MAXV][VEC];
+  u32x4 wraw[MAXV];  // norm weights, fetched with the row (packed: 4 registers per 16-byte vector)
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = threadIdx.x + i * blockDim.x;
     if (c < nvec) {
+      wraw[i] = *reinterpret_cast<const u32x4 *>(w + c * VEC);  // not a second round trip after the reduction
       load_vec<Tag>(xr + c * VEC, vals[i]);
       if constexpr (ADD) {
         typename elem<Tag>::T *rr = residual + (int64_t)row * res_stride + c * VEC;
@@ -79,7 +81,12 @@ __global__ void rmsnorm_kernel(const typename elem<Tag>::T *__restrict__ x, int6
     const int c = threadIdx.x + i * blockDim.x;
     if (c < nvec) {
       float wv[VEC], y[VEC];
-      load_vec<Tag>(w + c * VEC, wv);
+      if constexpr (VEC == 8) {
+        unpack8<Tag>(wraw[i], wv);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[j] = u2f(wraw[i][j]);
+      }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) y[j] = __fmul_rn(__fmul_rn(vals[i][j], rs), wv[j]);
       store_vec<Tag>(orow + c * VEC, y);
