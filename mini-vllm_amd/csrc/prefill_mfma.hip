@@ -195,14 +195,18 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
 
     // ---- S^T = K Q^T : two 32-key tiles (raw, unscaled scores; first k-step starts from an inline 0)
     f32x16 sacc[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    {
+      // the two 32-key accumulators alternate: a dependent MFMA issued right behind its predecessor waits
+      // for the whole 16-pass latency, an independent one issues as soon as the pipe is free
       const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const char *kt_base = ldsK + kt * 32 * ROW_BYTES;  // (row + 32) & 15 == row & 15: same swizzle
-      sacc[kt] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(kt_base + koff[0]), qf[0], zero16);
+      const char *k1 = ldsK + 32 * ROW_BYTES;  // (row + 32) & 15 == row & 15: same swizzle
+      sacc[0] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(ldsK + koff[0]), qf[0], zero16);
+      sacc[1] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(k1 + koff[0]), qf[0], zero16);
 #pragma unroll
-      for (int s = 1; s < NS; ++s)
-        sacc[kt] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(kt_base + koff[s]), qf[s], sacc[kt]);
+      for (int s = 1; s < NS; ++s) {
+        sacc[0] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(ldsK + koff[s]), qf[s], sacc[0]);
+        sacc[1] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(k1 + koff[s]), qf[s], sacc[1]);
+      }
     }
 
     // ---- mask (only tiles that touch the diagonal / the ragged end: wave-uniform branch)
@@ -261,20 +265,23 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
     // ---- O^T += V^T P^T   (rows 32kt + 16s2 + ... keep (row & 3) and ((row >> 2) & 3) of the base row:
     //      the swizzle term is loop invariant, only the row base moves by a multiple of 16 rows)
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const char *vb_ = ldsV + (kt * 32 + 16 * s2) * ROW_BYTES;
+        u32x4 a[NDT];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const char *vb_ = ldsV + (kt * 32 + 16 * s2) * ROW_BYTES;
+        for (int dt = 0; dt < NDT; ++dt) {
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(vb_ + voff_lo[dt]));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(vb_ + voff_hi[dt]));
           // the transposed read already delivers packed 16-bit pairs: reinterpret, do not repack
           const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
-          const u32x4 a = {lo2.x, lo2.y, hi2.x, hi2.y};
-          oacc[dt] = mfma<Tag>(a, pf[kt][s2], oacc[dt]);
+          a[dt] = u32x4{lo2.x, lo2.y, hi2.x, hi2.y};
         }
-    }
+        // four independent accumulators in a row (see QK^T above)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) oacc[dt] = mfma<Tag>(a[dt], pf[kt][s2], oacc[dt]);
+      }
     // registers -> the OTHER buffer (last read one iteration ago, behind the previous barrier), then the
     // single barrier of this tile: publishes tile t+1 and retires every wave's reads of tile t
     if (have_next) stage((t + 1) & 1);
