@@ -49,6 +49,11 @@ MODELS = {
                      intermediate_size=18944, vocab_size=152064, max_position_embeddings=32768,
                      rms_norm_eps=1e-6, rope_theta=1000000.0, tie_word_embeddings=False, hidden_act="silu",
                      torch_dtype="bfloat16", eos_token_id=151645),
+    "qwen2-72b": dict(model_type="qwen2", architectures=["Qwen2ForCausalLM"], hidden_size=8192,
+                      num_hidden_layers=80, num_attention_heads=64, num_key_value_heads=8,
+                      intermediate_size=29568, vocab_size=152064, max_position_embeddings=32768,
+                      rms_norm_eps=1e-6, rope_theta=1000000.0, tie_word_embeddings=False, hidden_act="silu",
+                      torch_dtype="bfloat16", eos_token_id=151645),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
