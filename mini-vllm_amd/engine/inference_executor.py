@@ -15,6 +15,7 @@ MI355X-first differences from the reference:
 from __future__ import annotations
 
 import logging
+import os
 
 import numpy as np
 import torch
@@ -86,6 +87,7 @@ class InferenceExecutor:
         self._samp_rows = -1  # rows of the device sampling planes that are current (-1: stale)
         # speculative next-step replay (see _replay_graph): set by the engine when nothing is waiting
         self.speculate_next = False
+        self.allow_speculation = os.environ.get("MV_DECODE_SPECULATE", "1") != "0"
         self._spec = None            # (batch, bucket, expected lens, event, host token slot) of the step in flight
         self._tok_host = [torch.zeros(ms, dtype=torch.int64, pin_memory=self.device.type == "cuda") for _ in range(3)]
         self._tok_events = [torch.cuda.Event() for _ in range(3)] if self.device.type == "cuda" else []
@@ -450,7 +452,7 @@ class InferenceExecutor:
             self._ship_sampling(sequences, b_pad=bs, unchanged=not inp.batch_changed)
             graph.replay()
             slot_now = self._stash_tokens(b)
-        if self.speculate_next and self._can_speculate(sequences):
+        if self.allow_speculation and self.speculate_next and self._can_speculate(sequences):
             self.sampler.calls += 1                          # the graph advanced the device-side offset itself
             graph.replay()
             self._spec = (list(sequences), bs, [s.num_tokens + 1 for s in sequences], self._stash_tokens(b), graph)

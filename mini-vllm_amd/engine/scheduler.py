@@ -24,6 +24,7 @@ class Scheduler:
         self.block_manager = BlockManager(config.num_kvcache_blocks, config.kvcache_block_size)
         self.waiting: deque[Sequence] = deque()
         self.running: deque[Sequence] = deque()
+        self.num_preemptions = 0
 
     def is_finished(self) -> bool:
         return not self.waiting and not self.running
@@ -118,6 +119,7 @@ class Scheduler:
 
     def preempt(self, sequence: Sequence) -> None:
         logger.info("Preempting sequence %d due to memory constraints.", sequence.seq_id)
+        self.num_preemptions += 1
         sequence.status = SequenceStatus.WAITING
         self.block_manager.deallocate(sequence)
         self.waiting.appendleft(sequence)

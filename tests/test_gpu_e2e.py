@@ -346,3 +346,63 @@ def test_kv_cache_auto_sizing_and_graph_buckets(golden_dir, tmp_path):
     assert att.k_cache.data_ptr() == ex.kv_cache[0, 1].data_ptr() and att.v_cache.data_ptr() == ex.kv_cache[1, 1].data_ptr()
     assert graph_batch_sizes(256) == [1, 2, 4, 8, 12] + list(range(16, 257, 16))
     assert graph_batch_sizes(8) == [1, 2, 4, 8] and graph_batch_sizes(1000)[-1] == 512
+
+
+def test_randomized_serving_speculation_changes_nothing(golden_dir, tmp_path, monkeypatch):
+    """Continuous batching under pressure: 40 requests with random lengths / budgets / shared prefixes
+    arriving while others decode, a KV pool small enough to force preemption and recomputation, prefix-cache
+    hits, block edges, EOS stops.  The captured-graph path is run twice, with and without the speculative
+    replay of the next step: every request must get exactly the same tokens (same buckets, same kernels; the
+    speculation only changes WHEN a step is enqueued).  Against eager decoding the batch is padded to a
+    bucket, which may move a split-KV boundary, so only agreement of nearly all requests is asked there."""
+    import random
+
+    from minivllm_amd import LLM, Config, SamplingParams
+
+    z = _load(golden_dir, "qwen3")
+    d = tmp_path / "m"
+    d.mkdir()
+    (d / "config.json").write_text(bytes(z["config_json"]).decode())
+    weights = {k[2:]: torch.from_numpy(z[k].view(np.int16).copy()).view(torch.bfloat16).float()
+               for k in z.files if k.startswith("w:")}
+    rng = random.Random(7)
+    shared = [rng.randrange(3, 300) for _ in range(70)]                   # > one block: prefix-cache hits
+    reqs = []
+    for i in range(40):
+        body = [rng.randrange(3, 300) for _ in range(rng.choice((1, 5, 20, 62, 63, 64, 65, 100)))]
+        prompt = (shared + body) if i % 3 == 0 else body
+        reqs.append((prompt, SamplingParams(temperature=0.0, max_tokens=rng.choice((1, 2, 7, 20, 33, 70)),
+                                            ignore_eos=(i % 4 != 0)), rng.randrange(0, 60)))
+
+    def serve(eager, speculate):
+        monkeypatch.setenv("MV_DECODE_SPECULATE", "1" if speculate else "0")
+        cfg = Config(str(d), max_model_len=512, max_num_batched_tokens=512, max_num_seqs=8, enforce_eager=eager,
+                     dtype="bfloat16", num_kvcache_blocks=14, load_format="dummy", seed=0)
+        engine = LLM(cfg)
+        engine.model_runner.model_manager.model.load_weights(weights)
+        engine.scheduler.eos = 17
+        pending = sorted(range(len(reqs)), key=lambda i: reqs[i][2])
+        ids, done, step = {}, {}, 0
+        while pending or not engine.is_finished():
+            while pending and reqs[pending[0]][2] <= step:
+                i = pending.pop(0)
+                ids[engine.add_request(reqs[i][0], reqs[i][1])] = i
+            if not engine.is_finished():
+                outs, _ = engine.step()
+                for sid, toks in outs:
+                    done[ids[sid]] = toks
+            step += 1
+            assert step < 5000
+        ex = engine.model_runner.inference_executor
+        stats = (ex.spec_hits, ex.spec_misses, engine.scheduler.num_preemptions)
+        engine.exit()
+        return [done[i] for i in range(len(reqs))], stats
+
+    plain, st0 = serve(eager=False, speculate=False)
+    spec, st1 = serve(eager=False, speculate=True)
+    assert st0[0] == 0 and st1[0] > 20, (st0, st1)                      # really speculated (arrivals discard some)
+    assert st0[2] == st1[2] > 0, (st0, st1)                             # the pool did run dry: preemptions
+    assert spec == plain
+    eager, _ = serve(eager=True, speculate=False)
+    assert [len(t) for t in eager] == [len(t) for t in plain] or sum(a == b for a, b in zip(eager, plain)) >= 36
+    assert sum(a == b for a, b in zip(eager, plain)) >= 36
