@@ -17,7 +17,6 @@ from __future__ import annotations
 import logging
 import os
 
-import numpy as np
 import torch
 
 from ..config import Config

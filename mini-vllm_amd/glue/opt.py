@@ -6,7 +6,6 @@ from __future__ import annotations
 
 from typing import Any
 
-import torch
 import torch.nn.functional as F
 from torch import nn
 

@@ -12,7 +12,6 @@ from __future__ import annotations
 
 from typing import Any
 
-import torch
 from torch import nn
 
 from .. import hip_ops

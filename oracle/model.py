@@ -11,7 +11,6 @@ tests/golden/e2e_*.npz (tests/test_oracle_model.py).  Used as
 """
 from __future__ import annotations
 
-import math
 from types import SimpleNamespace
 
 import torch
