@@ -217,6 +217,18 @@ int mv_ar_status(void *base, size_t max_bytes, uint32_t *status_out);
 int mv_ar_all_reduce(const void *x, void *out, int64_t n, void *const *bases,
                      int rank, int world, size_t max_bytes, int dtype, void *stream);
 
+/* f1 — all-reduce + residual add + RMSNorm in one launch (same regions and protocol as mv_ar_all_reduce,
+ * rows as the unit): x [m][k] = this rank's partial sums; afterwards
+ *   residual <- (dtype(sum over ranks of x) + residual) -> dtype          (in place)
+ *   out      <- ((s * rsqrt(mean(s^2)+eps)) * norm_w) -> dtype,  s the unrounded fp32 sum above
+ * = dist.all_reduce (minivllm/models/layers/linear.py:316-318) + RMSNorm.add_rms_forward
+ * (layers/layernorm.py:95-105), rounding points of the unfused pair.  norm_w == NULL: out <- the plain
+ * row-wise all-reduce, residual untouched.  m % world == 0, k % 8 == 0, k <= 4096, m*k*2 <= max_bytes. */
+int mv_ar_all_reduce_add_rmsnorm(const void *x, void *residual, const void *norm_w,
+                                 float eps, void *out, int m, int k,
+                                 void *const *bases, int rank, int world,
+                                 size_t max_bytes, int dtype, void *stream);
+
 /* f2 — greedy decoding under tensor parallelism without the logit all-gather (replaces, for all-greedy
  * batches, the gather of ParallelLMHead.forward, minivllm/models/layers/embed_head.py:219-229, + argmax).
  * mv_greedy_pack: buf [world][rows_padded][4] (16-bit dtype) <- zeros, except slot [rank][r] =

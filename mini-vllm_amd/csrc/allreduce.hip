@@ -101,7 +101,6 @@ __device__ __forceinline__ void peer_barrier(const ArParams &p, const ArRegion &
 
 template <typename Tag>
 __global__ void __launch_bounds__(kArThreads) allreduce_two_shot_kernel(ArParams p) {
-  typedef uint16_t T;
   const ArRegion L = ar_layout(p.max_bytes);
   char *self = p.base[p.rank];
   uint32_t *epoch_p = (uint32_t *)(self + L.epoch_off);
@@ -169,6 +168,136 @@ __global__ void __launch_bounds__(kArThreads) allreduce_two_shot_kernel(ArParams
   }
 }
 
+// f1 — all-reduce + residual add + RMSNorm in ONE launch, for a [M, K] activation with
+// M % world == 0: the same two-shot protocol with ROWS as the unit.  Row r belongs to slice r / (M/W) (the
+// rank that reduces it) and to block r % NB on every rank (so the per-block barriers cover every hand-off);
+// inside a block, wave (r / NB) % 8 owns it: a whole row per wave, the row norm is a wave reduction, no LDS.
+//   0. copy my rows into staging   1. barrier   2. reduce the rows of my slice (fp32, rank order, -> dtype)
+//   3. barrier   4. per row: fetch the reduced row from its owner, s = f32(sum) + f32(residual),
+//      residual <- s -> dtype (in place), out <- ((s * rsqrt(mean(s^2)+eps)) * w) -> dtype
+// i.e. dist.all_reduce followed by RMSNorm.add_rms_forward (minivllm/models/layers/linear.py:316-318,
+// layers/layernorm.py:95-105) with the rounding points of the unfused pair (the sum is rounded to dtype
+// before the residual is added).  norm_w == nullptr: plain row-wise all-reduce into out.
+constexpr int kRowVecMax = 8;  // 16-byte vectors per lane and row: K <= 4096 (template NV = 4 or 8; a whole row of
+                               // K = 8192 per wave would spill: such models keep the unfused pair)
+
+struct ArRowParams {
+  ArParams ar;        // x = [M][K] partial sums (row stride K), out = normed output (or the plain sum)
+  void *residual;     // [M][K], in/out; nullptr with norm_w == nullptr
+  const void *norm_w; // [K]
+  int M, K;
+  float eps;
+};
+
+template <typename Tag, int NV>
+__global__ void __launch_bounds__(kArThreads) allreduce_rows_kernel(ArRowParams rp) {
+  const ArParams &p = rp.ar;
+  const ArRegion L = ar_layout(p.max_bytes);
+  char *self = p.base[p.rank];
+  uint32_t *epoch_p = (uint32_t *)(self + L.epoch_off);
+  uint32_t *status = (uint32_t *)(self + L.status_off);
+  const uint32_t epoch = __hip_atomic_load(epoch_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const int parity = epoch & 1;
+  const int W = p.world, NB = gridDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = kArThreads / 64;
+  const int nv = rp.K >> 3;                 // vectors per row
+  const int Ms = rp.M / W;                  // rows per slice
+  const size_t stage_off = (size_t)parity * L.staging_bytes;
+  u32x4 *mine = (u32x4 *)(self + stage_off);
+  const u32x4 *xin = (const u32x4 *)p.x;
+
+  // rows of this (block, wave): r = blockIdx.x + NB * (wave + nw * i)
+  // 0. copy-in
+  for (int r = blockIdx.x + NB * wave; r < rp.M; r += NB * nw)
+    for (int v = lane; v < nv; v += 64) mine[(int64_t)r * nv + v] = xin[(int64_t)r * nv + v];
+  peer_barrier(p, L, parity, 0, epoch, status);
+
+  // 2. reduce the rows of slice `rank`
+  for (int r = blockIdx.x + NB * wave; r < rp.M; r += NB * nw) {
+    if (r / Ms != p.rank) continue;
+    for (int v = lane; v < nv; v += 64) {
+      const uint32_t off = (uint32_t)(((int64_t)r * nv + v) * 16);
+      u32x4 in[kMaxWorld];
+#pragma unroll
+      for (int q = 0; q < kMaxWorld; ++q)
+        if (q < W) in[q] = load_sys(make_rsrc(p.base[q] + stage_off, L.staging_bytes), off);
+      float acc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int q = 0; q < kMaxWorld; ++q)
+        if (q < W) {
+          float f[8];
+          unpack8<Tag>(in[q], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += f[e];
+        }
+      mine[(int64_t)r * nv + v] = pack8<Tag>(acc);
+    }
+  }
+  peer_barrier(p, L, parity, 1, epoch, status);
+
+  // 4. gather (+ residual add + RMSNorm): one row per wave at a time, the row stays in registers
+  u32x4 *out = (u32x4 *)p.out;
+  u32x4 *res = (u32x4 *)rp.residual;
+  const u32x4 *nwp = (const u32x4 *)rp.norm_w;
+  for (int r = blockIdx.x + NB * wave; r < rp.M; r += NB * nw) {
+    const int owner = r / Ms;
+    u32x4 a[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = lane + 64 * i;
+      if (v < nv) {
+        a[i] = load_sys(make_rsrc(p.base[owner] + stage_off, L.staging_bytes), (uint32_t)(((int64_t)r * nv + v) * 16));
+        if (nwp) b[i] = res[(int64_t)r * nv + v];
+      }
+    }
+    if (!nwp) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < nv) out[(int64_t)r * nv + lane + 64 * i] = a[i];
+      continue;
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nv) {
+        float fa[8], fb[8];
+        unpack8<Tag>(a[i], fa);
+        unpack8<Tag>(b[i], fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          fa[e] = __fadd_rn(fa[e], fb[e]);
+          ss = fmaf(fa[e], fa[e], ss);
+        }
+        res[(int64_t)r * nv + lane + 64 * i] = pack8<Tag>(fa);  // residual <- (sum + residual) -> dtype
+      }
+    ss = wave_sum(ss);
+    const float rs = 1.0f / sqrtf(ss / (float)rp.K + rp.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nv) {
+        float fa[8], fb[8], fw[8], y[8];
+        unpack8<Tag>(a[i], fa);
+        unpack8<Tag>(b[i], fb);
+        unpack8<Tag>(nwp[lane + 64 * i], fw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = __fmul_rn(__fmul_rn(__fadd_rn(fa[e], fb[e]), rs), fw[e]);
+        out[(int64_t)r * nv + lane + 64 * i] = pack8<Tag>(y);
+      }
+  }
+
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t *done = epoch_p + 1;
+    const uint32_t t = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (uint32_t)gridDim.x - 1) {
+      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(epoch_p, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // f2: greedy decoding under tensor parallelism without gathering the logits.  Every rank packs,
 // per row, the maximum of its vocab shard and the global index of that maximum into four 16-bit floats that
 // are EXACT in bf16/f16 (the logit itself; three 8-bit pieces of the index) at slot [rank] of a zeroed
@@ -211,6 +340,49 @@ __global__ void greedy_merge_kernel(const uint16_t *buf, int world, int rows, in
 }
 
 }  // namespace
+
+extern "C" int mv_ar_all_reduce_add_rmsnorm(const void *x, void *residual, const void *norm_w, float eps, void *out,
+                                            int m, int k, void *const *bases, int rank, int world,
+                                            size_t max_bytes, int dtype, void *stream) {
+  if (m == 0) return MV_OK;
+  if (!x || !out || !bases || (norm_w && !residual)) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (world < 2 || world > kMaxWorld || rank < 0 || rank >= world) return MV_E_RANGE;
+  if (m < 0 || k <= 0 || (m % world) != 0 || (k & 7) || k > 8 * 64 * kRowVecMax ||
+      (size_t)m * (size_t)k * 2 > max_bytes)
+    return MV_E_SHAPE;
+  if (!mv_aligned16(x) || !mv_aligned16(out) || (residual && !mv_aligned16(residual)) ||
+      (norm_w && !mv_aligned16(norm_w)))
+    return MV_E_ALIGN;
+  ArRowParams rp;
+  for (int q = 0; q < kMaxWorld; ++q) rp.ar.base[q] = q < world ? (char *)bases[q] : nullptr;
+  for (int q = 0; q < world; ++q)
+    if (!rp.ar.base[q]) return MV_E_NULLPTR;
+  rp.ar.x = x;
+  rp.ar.out = out;
+  rp.ar.max_bytes = max_bytes;
+  rp.ar.n = (int64_t)m * k;
+  rp.ar.rank = rank;
+  rp.ar.world = world;
+  rp.residual = residual;
+  rp.norm_w = norm_w;
+  rp.M = m;
+  rp.K = k;
+  rp.eps = eps;
+  const int nvl = (k / 8 + 63) / 64;  // vectors per lane and row
+  const dim3 grid(kArBlocks), block(kArThreads);
+  hipStream_t st = (hipStream_t)stream;
+#define MV_AR_ROWS(TAG)                                                                                   \
+  do {                                                                                                    \
+    if (nvl <= 4) hipLaunchKernelGGL((allreduce_rows_kernel<TAG, 4>), grid, block, 0, st, rp);          \
+    else hipLaunchKernelGGL((allreduce_rows_kernel<TAG, 8>), grid, block, 0, st, rp);                   \
+  } while (0)
+  if (dtype == MV_BF16) MV_AR_ROWS(bf16_tag);
+  else MV_AR_ROWS(f16_tag);
+#undef MV_AR_ROWS
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
 
 extern "C" int mv_greedy_pack(const void *logits_local, int64_t ld, const int64_t *local_tokens, int rank, int world,
                               int64_t vocab_per_rank, int rows, int rows_padded, void *buf, int dtype,

@@ -114,6 +114,23 @@ class CustomAllReduce:
                 for want, got, inplace in pairs:
                     dist.all_reduce(want, group=self.group)
                     good = good and torch.equal(got, want) and torch.equal(inplace, want)
+        # the fused all-reduce + add + RMSNorm launch against the unfused pair (exact sums -> identical inputs
+        # to the norm; the row norm itself may differ in the last bit of rstd: compare within 2 ulp)
+        for dtype, (m, k) in ((torch.bfloat16, (8 * self.world, 2048)), (torch.float16, (self.world, 3584)),
+                              (torch.bfloat16, (256, 2048))):
+            if m % self.world:
+                m += self.world - m % self.world
+            for _ in range(3):
+                x = torch.randint(-6, 7, (m, k), generator=gen).to(dtype).to(self.device)
+                res = torch.randn((m, k), generator=gen).to(dtype).to(self.device)
+                w = (1 + 0.1 * torch.randn(k, generator=gen)).to(dtype).to(self.device)
+                summed = x.clone()
+                dist.all_reduce(summed, group=self.group)
+                want, want_res = hip_ops.add_rmsnorm(summed, res.clone(), w, 1e-6)
+                got, got_res = self.all_reduce_add_rmsnorm(x, res.clone(), w, 1e-6)
+                eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+                good = (good and torch.equal(got_res, want_res)
+                        and bool(((got.float() - want.float()).abs() <= 2 * eps * want.float().abs() + 1e-6).all()))
         return good and self.status() == 0
 
     # ------------------------------------------------------------------ use
@@ -133,6 +150,23 @@ class CustomAllReduce:
     def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
         """In-place SUM over the ranks (``accepts(x)`` must hold)."""
         return self._launch(x, None)
+
+    def accepts_rows(self, x: torch.Tensor) -> bool:
+        """[M, K] activations the fused all-reduce + add + RMSNorm launch takes."""
+        return (self.accepts(x) and x.dim() == 2 and x.shape[0] % self.world == 0 and x.shape[1] % 8 == 0
+                and x.shape[1] <= 4096)
+
+    def all_reduce_add_rmsnorm(self, x, residual, norm_weight, eps: float):
+        """-> (normed, residual): ``x`` summed over the ranks, added to ``residual`` (updated in place),
+        RMS-normalised (``accepts_rows(x)`` must hold) -- dist.all_reduce + RMSNorm.add_rms_forward, one launch."""
+        out = torch.empty_like(x)
+        nw = norm_weight if norm_weight.dtype == x.dtype else norm_weight.to(x.dtype)
+        hip_ops._check(_lib.mv_ar_all_reduce_add_rmsnorm(
+            x.data_ptr(), residual.data_ptr(), nw.data_ptr(), float(eps), out.data_ptr(), x.shape[0], x.shape[1],
+            self.bases, self.rank, self.world, self.max_bytes, hip_ops._dt(x), hip_ops._stream()),
+            "mv_ar_all_reduce_add_rmsnorm")
+        self.calls += 1
+        return out, residual
 
     def status(self) -> int:
         """0 while every peer wait of every call so far was satisfied (host call: synchronises the device)."""

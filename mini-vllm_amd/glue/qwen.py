@@ -18,7 +18,7 @@ from .. import hip_ops
 from ..layers import (Attention, MergedColumnParallelLinear, ParallelLMHead, QKVParallelLinear, RMSNorm,
                       RowParallelLinear, SiluAndMul, VocabParallelEmbedding, get_rope)
 from ..layers.linear import small_m
-from ..parallel_state import get_tensor_parallel_world_size
+from ..parallel_state import get_tensor_parallel_world_size, tp_all_reduce_add_rmsnorm
 from ..utils.context import get_context
 
 __all__ = ["QwenAttention", "QwenMLP", "QwenDecoderLayer", "QwenModel", "QwenForCausalLM",
@@ -77,7 +77,7 @@ class QwenAttention(nn.Module):
         self.q_norm = None if qkv_bias else RMSNorm(self.head_dim, eps=rms_norm_eps)
         self.k_norm = None if qkv_bias else RMSNorm(self.head_dim, eps=rms_norm_eps)
 
-    def forward(self, positions, hidden_states):
+    def forward(self, positions, hidden_states, reduce: bool = True):
         lead = hidden_states.shape[:-1]
         if hidden_states.dim() == 3:  # [B,S,h]: same math on the flattened tokens
             hidden_states = hidden_states.reshape(-1, hidden_states.shape[-1])
@@ -101,7 +101,7 @@ class QwenAttention(nn.Module):
             attn.k_cache if has_cache else None, attn.v_cache if has_cache else None,
             ctx.slot_mapping if has_cache else None, want_k_out=want_k)
         o = attn(q_rot, k_rot, v, kv_stored=True)
-        out = self.o_proj(o.view(t, self.q_size))
+        out = self.o_proj(o.view(t, self.q_size), reduce=reduce)
         return out.view(*lead, out.shape[-1])
 
     def extra_repr(self) -> str:
@@ -119,11 +119,11 @@ class QwenMLP(nn.Module):
         self.act_fn = SiluAndMul()
         self.hidden_act, self.intermediate_size, self.hidden_size = hidden_act, intermediate_size, hidden_size
 
-    def forward(self, x):
+    def forward(self, x, reduce: bool = True):
         w = self.gate_up_proj.weight
         if small_m(x, w):  # decode-sized batch: SiluAndMul in the epilogue of the weight-streaming gate_up kernel
-            return self.down_proj(hip_ops.gate_up_silu_small_m(x, w))
-        return self.down_proj(self.act_fn(self.gate_up_proj(x)))
+            return self.down_proj(hip_ops.gate_up_silu_small_m(x, w), reduce=reduce)
+        return self.down_proj(self.act_fn(self.gate_up_proj(x)), reduce=reduce)
 
 
 class QwenDecoderLayer(nn.Module):
@@ -142,15 +142,30 @@ class QwenDecoderLayer(nn.Module):
         self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
-    def forward(self, positions, hidden_states, residual):
+    def forward(self, positions, hidden_states, residual, pending_reduce: bool = False):
+        """``pending_reduce``: ``hidden_states`` is the previous layer's un-reduced down_proj output (tensor
+        parallel): its all-reduce runs fused with this layer's input norm.  Under TP the layer defers both of
+        its own all-reduces the same way and returns the un-reduced MLP output (see ``defers_reduce``)."""
+        ln1, ln2, defer = self.input_layernorm, self.post_attention_layernorm, self.defers_reduce
         if residual is None:
             residual = hidden_states
-            hidden_states, _ = self.input_layernorm(hidden_states)
+            hidden_states, _ = ln1(hidden_states)
+        elif pending_reduce:
+            hidden_states, residual = tp_all_reduce_add_rmsnorm(hidden_states, residual, ln1.weight, ln1.eps)
         else:
-            hidden_states, residual = self.input_layernorm(hidden_states, residual)
-        hidden_states = self.self_attn(positions, hidden_states)
-        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
-        return self.mlp(hidden_states), residual
+            hidden_states, residual = ln1(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states, reduce=not defer)
+        if defer:
+            hidden_states, residual = tp_all_reduce_add_rmsnorm(hidden_states, residual, ln2.weight, ln2.eps)
+        else:
+            hidden_states, residual = ln2(hidden_states, residual)
+        return self.mlp(hidden_states, reduce=not defer), residual
+
+    @property
+    def defers_reduce(self) -> bool:
+        """Tensor parallel, 2-D token-major activations: the all-reduces after o_proj / down_proj are issued
+        together with the residual add + RMSNorm behind them (one launch on the peer-to-peer kernel)."""
+        return get_tensor_parallel_world_size() > 1
 
 
 class QwenModel(nn.Module):
@@ -164,10 +179,14 @@ class QwenModel(nn.Module):
         self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
     def forward(self, input_ids, positions):
-        hidden_states, residual = self.embed_tokens(input_ids), None
+        hidden_states, residual, pending = self.embed_tokens(input_ids), None, False
         for layer in self.layers:
-            hidden_states, residual = layer(positions, hidden_states, residual)
-        hidden_states, _ = self.norm(hidden_states, residual)
+            hidden_states, residual = layer(positions, hidden_states, residual, pending)
+            pending = layer.defers_reduce
+        if pending:   # the last layer's down_proj is still un-reduced
+            hidden_states, _ = tp_all_reduce_add_rmsnorm(hidden_states, residual, self.norm.weight, self.norm.eps)
+        else:
+            hidden_states, _ = self.norm(hidden_states, residual)
         return hidden_states
 
 

@@ -61,6 +61,8 @@ _SIGNATURES = {
     "mv_ar_ipc_close": (c_int, [c_void_p]),
     "mv_ar_status": (c_int, [c_void_p, c_size_t, c_void_p]),
     "mv_ar_all_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_size_t, c_int, c_void_p]),
+    "mv_ar_all_reduce_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p,
+                                             c_int, c_int, c_size_t, c_int, c_void_p]),
     "mv_greedy_pack": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int,
                                c_void_p]),
     "mv_greedy_merge": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -137,6 +137,8 @@ class RowParallelLinear(LinearBase):
         shard = param.data.size(1)
         param.data.copy_(loaded_weight.narrow(1, self.tp_rank * shard, shard))
 
-    def forward(self, x):
+    def forward(self, x, reduce: bool = True):
+        """``reduce=False`` returns this rank's partial product: the caller sums it together with the
+        residual add + RMSNorm that follows (parallel_state.tp_all_reduce_add_rmsnorm)."""
         y = linear(x, self.weight, self.bias if self.tp_rank == 0 else None)
-        return tp_all_reduce(y) if self.tp_size > 1 else y
+        return tp_all_reduce(y) if self.tp_size > 1 and reduce else y

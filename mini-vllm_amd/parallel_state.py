@@ -55,6 +55,19 @@ def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def tp_all_reduce_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float):
+    """``tp_all_reduce(x)`` followed by the fused residual-add + RMSNorm -> (normed, residual), residual
+    updated in place.  One launch on the peer-to-peer kernel when it takes the shape,
+    otherwise the two steps."""
+    from . import hip_ops
+
+    ar = _state["custom_ar"]
+    if (ar is not None and ar.accepts_rows(x) and residual.shape == x.shape and residual.dtype == x.dtype
+            and residual.is_contiguous()):
+        return ar.all_reduce_add_rmsnorm(x, residual, weight, eps)
+    return hip_ops.add_rmsnorm(tp_all_reduce(x), residual, weight, eps, inplace=True)
+
+
 def tp_all_gather_stack(x: torch.Tensor) -> torch.Tensor:
     """``[tp, *x.shape]``: every rank's ``x``, rank-major, on every rank."""
     n = _state["size"]

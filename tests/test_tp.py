@@ -229,6 +229,26 @@ def _custom_ar_worker(rank, world, port, out_path):
             # fp32 accumulation, one rounding: within half an ulp of the exact sum
             eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
             errs.append(bool(((got.float() - want).abs() <= eps * want.abs() + 1e-6).all()))
+        # all-reduce + residual add + RMSNorm in one launch == the two steps (same sum bits -> same residual
+        # bits; the row norm may differ in the last bit of rstd)
+        from minivllm_amd import hip_ops
+
+        for (m, k), dtype in (((4 * world, 2048), torch.bfloat16), ((world, 3584), torch.float16),
+                              ((256, 1024), torch.bfloat16)):
+            x = torch.randn((m, k), generator=g).to(dtype).cuda()
+            res = torch.randn((m, k), generator=g).to(dtype).cuda()
+            w = (1 + 0.1 * torch.randn(k, generator=g)).to(dtype).cuda()
+            want, want_res = hip_ops.add_rmsnorm(parallel_state.tp_all_reduce(x.clone()), res.clone(), w, 1e-6)
+            res_in = res.clone()
+            got, got_res = parallel_state.tp_all_reduce_add_rmsnorm(x.clone(), res_in, w, 1e-6)
+            eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+            errs.append(got_res is res_in and torch.equal(got_res, want_res)
+                        and bool(((got.float() - want.float()).abs() <= 2 * eps * want.float().abs() + 1e-6).all()))
+        # shapes the fused launch does not take fall back to the two steps
+        odd = torch.randn((world + 1, 2048), generator=g).to(torch.bfloat16).cuda()
+        o1, _ = parallel_state.tp_all_reduce_add_rmsnorm(odd.clone(), torch.zeros_like(odd), torch.ones(2048).bfloat16().cuda(), 1e-6)
+        o2, _ = hip_ops.add_rmsnorm(parallel_state.tp_all_reduce(odd.clone()), torch.zeros_like(odd), torch.ones(2048).bfloat16().cuda(), 1e-6)
+        errs.append(not ar.accepts_rows(odd) and torch.equal(o1, o2))
         calls = ar.calls
         big = torch.zeros(4 << 20, dtype=torch.bfloat16, device="cuda")      # 8 MiB + : above the limit -> backend
         odd = torch.zeros(8 * world + 8, dtype=torch.bfloat16, device="cuda")[:-8] if world > 1 else None
