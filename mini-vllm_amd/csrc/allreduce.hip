@@ -29,7 +29,7 @@ namespace {
 constexpr int kMaxWorld = 8;
 constexpr int kArBlocks = 32;       // workgroups per launch (= flag slots per rank and phase)
 constexpr int kArThreads = 512;
-constexpr int kSpinLimit = 4000000;  // bounded wait: ~seconds of polling, then give up
+constexpr int kSpinLimit = 20000000;  // bounded wait: tens of seconds of polling, then give up
 
 struct ArRegion {
   // byte offsets inside a rank's region

@@ -74,6 +74,10 @@ class CustomAllReduce:
                                "mv_ar_ipc_open")
                 self.peers[q] = ptr.value
                 self.bases[q] = ptr.value
+            # load this library's code object NOW (HIP loads it at the first launch): a rank that spends
+            # seconds on that inside the first collective call would make its peers' bounded waits give up
+            hip_ops.greedy_merge(torch.zeros((self.world, 2, 4), dtype=torch.bfloat16, device=self.device), 1)
+            torch.cuda.synchronize(self.device)
         except Exception as e:  # noqa: BLE001
             logger.warning("custom all-reduce: IPC open failed on rank %d: %s", self.rank, e)
             ok = False
@@ -111,9 +115,14 @@ class CustomAllReduce:
                     got = self._launch(x, torch.empty_like(x))
                     inplace = self._launch(x.clone(), None)
                     pairs.append((want, got, inplace))
-                for want, got, inplace in pairs:
+                for i, (want, got, inplace) in enumerate(pairs):
                     dist.all_reduce(want, group=self.group)
-                    good = good and torch.equal(got, want) and torch.equal(inplace, want)
+                    ok = torch.equal(got, want) and torch.equal(inplace, want)
+                    if not ok and good:
+                        logger.warning("custom all-reduce validation: mismatch on rank %d (%s, n=%d, call %d, "
+                                       "%d / %d elements differ, status %d)", self.rank, dtype, n, i,
+                                       int((got != want).sum()), int((inplace != want).sum()), self.status())
+                    good = good and ok
         # the fused all-reduce + add + RMSNorm launch against the unfused pair (exact sums -> identical inputs
         # to the norm; the row norm itself may differ in the last bit of rstd: compare within 2 ulp)
         for dtype, (m, k) in ((torch.bfloat16, (8 * self.world, 2048)), (torch.float16, (self.world, 3584)),
@@ -129,9 +138,17 @@ class CustomAllReduce:
                 want, want_res = hip_ops.add_rmsnorm(summed, res.clone(), w, 1e-6)
                 got, got_res = self.all_reduce_add_rmsnorm(x, res.clone(), w, 1e-6)
                 eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
-                good = (good and torch.equal(got_res, want_res)
-                        and bool(((got.float() - want.float()).abs() <= 2 * eps * want.float().abs() + 1e-6).all()))
-        return good and self.status() == 0
+                ok = (torch.equal(got_res, want_res)
+                      and bool(((got.float() - want.float()).abs() <= 2 * eps * want.float().abs() + 1e-6).all()))
+                if not ok and good:
+                    logger.warning("custom all-reduce validation: fused add+RMSNorm mismatch on rank %d (%s, %dx%d, "
+                                   "residual equal: %s, status %d)", self.rank, dtype, m, k,
+                                   torch.equal(got_res, want_res), self.status())
+                good = good and ok
+        st = self.status()
+        if st != 0:
+            logger.warning("custom all-reduce validation: a peer wait timed out on rank %d", self.rank)
+        return good and st == 0
 
     # ------------------------------------------------------------------ use
     def accepts(self, x: torch.Tensor) -> bool:

@@ -67,6 +67,7 @@ class InferenceExecutor:
         self.graph_bs: list[int] = []
         self.graph_vars: dict[str, torch.Tensor] = {}
         self.graph_pool = None
+        self._general_capture = "no"   # "done" | "lazy" (first sampled batch under TP) | "no"
         self.total_tokens_generated = self.total_prefill_tokens = self.total_decode_tokens = 0
         self.inference_count = 0
         self.max_blocks_per_seq = -(-config.max_model_len // self.block_size)
@@ -298,7 +299,12 @@ class InferenceExecutor:
         """Smallest captured bucket that holds the batch, in the graph family the batch decodes with."""
         if self.enforce_eager:
             return None
-        family = self.greedy_graphs if self.greedy_graphs and self._tp_greedy(sequences) else self.graphs
+        greedy = bool(self.greedy_graphs) and self._tp_greedy(sequences)
+        if not greedy and self._general_capture == "lazy":
+            self._spec = None
+            torch.cuda.synchronize(self.device)
+            self._capture_general()
+        family = self.greedy_graphs if greedy else self.graphs
         return next((bs for bs in self.graph_bs if bs >= len(sequences) and bs in family), None)
 
     def capture_device_graphs(self, max_batch_size: int) -> None:
@@ -340,20 +346,17 @@ class InferenceExecutor:
                                                                    self.block_size, self.max_blocks_per_seq)
                               for bs in self.graph_bs), dev)
         self.sampler.offset_dev = gv["rng_offset"]
+        self._general_capture = "no" if not general_ok else "done"
         try:
-            if self.tp_size > 1:   # first the family without a backend collective inside
+            if self.tp_size > 1:   # the family without a backend collective inside (peer-to-peer kernels only)
                 for bs in reversed(self.graph_bs):
                     self._capture_one(bs, greedy=True)
-            try:
-                for bs in reversed(self.graph_bs):
-                    if general_ok:
-                        self._capture_one(bs, greedy=False)
-            except Exception as e:
-                if not self.greedy_graphs:
-                    raise
-                logger.warning("Failed to capture the gathered-logits graphs (sampled batches decode eagerly): %s", e)
-                self.graphs.clear()
-                self._recover_from_failed_capture()
+                if general_ok and self.greedy_graphs and decode_step_is_native(self.dtype, hf.hidden_size, hf.vocab_size):
+                    # the gathered-logits family needs RCCL nodes in its graphs: captured on the first batch with
+                    # a sampled row (_graph_bucket), so that a greedy-only workload never captures a collective
+                    self._general_capture = "lazy"
+            if self._general_capture == "done":
+                self._capture_general()
             logger.info("Captured %d decode graphs (batch sizes %s..%d)", len(self.graphs) + len(self.greedy_graphs),
                         self.graph_bs[:4], self.graph_bs[-1])
         except Exception as e:  # fall back to eager, loudly
@@ -362,6 +365,22 @@ class InferenceExecutor:
             self.greedy_graphs.clear()
             self.graph_pool = None
             self.sampler.offset_dev = None
+            self._general_capture = "no"
+            self._recover_from_failed_capture()
+
+    def _capture_general(self) -> None:
+        """The gathered-logits graphs (every sampling mode).  Under TP a failure here only sends batches with
+        sampled rows to eager decoding: the all-greedy graphs stay."""
+        try:
+            for bs in reversed(self.graph_bs):
+                self._capture_one(bs, greedy=False)
+            self._general_capture = "done"
+        except Exception as e:
+            if not self.greedy_graphs:
+                raise
+            logger.warning("Failed to capture the gathered-logits graphs (sampled batches decode eagerly): %s", e)
+            self.graphs.clear()
+            self._general_capture = "no"
             self._recover_from_failed_capture()
 
     def _recover_from_failed_capture(self) -> None:
