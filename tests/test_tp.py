@@ -213,8 +213,10 @@ def _custom_ar_worker(rank, world, port, out_path):
     from minivllm_amd import parallel_state
     from minivllm_amd.custom_allreduce import maybe_create
 
-    ar = maybe_create(rank, world, torch.device("cuda", 0))
-    ok = ar is not None                                # set-up includes the exact validation against gloo
+    # set-up includes the exact validation against gloo; its verdict is collective, so a retry (a box busy
+    # enough to exhaust a bounded wait) is taken by every rank together
+    ar = maybe_create(rank, world, torch.device("cuda", 0)) or maybe_create(rank, world, torch.device("cuda", 0))
+    ok = ar is not None
     errs = []
     if ok:
         parallel_state.set_custom_all_reduce(ar)
