@@ -303,8 +303,10 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
         llm = LLM(Config(str(d), dtype=dtype, tensor_parallel_size=tp, **{**kw, "enforce_eager": eager}))
         try:
             ex = llm.model_runner.inference_executor
+            from minivllm_amd import parallel_state
+
             out = [o_["token_ids"] for o_ in llm.generate(prompts, sp, use_tqdm=False)]
-            return out, bool(ex.greedy_graphs), ex.spec_hits
+            return out, bool(ex.greedy_graphs), ex.spec_hits, parallel_state.get_custom_all_reduce() is not None
         finally:
             llm.exit()
 
@@ -313,12 +315,14 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
     assert run(2, "float32")[0] == run(1, "float32")[0]
     # bf16 (all-reduces on the peer-to-peer kernel): same lengths, and the first tokens agree (later ones may
     # legitimately diverge after a near-tie, as between any two bf16 summation orders)
-    (a, _, _), (b, _, _) = run(2, "bfloat16"), run(1, "bfloat16")
+    (a, *_), (b, *_) = run(2, "bfloat16"), run(1, "bfloat16")
     assert [len(t) for t in a] == [len(t) for t in b] == [12] * len(prompts)
     assert sum(x[0] == y[0] for x, y in zip(a, b)) >= len(prompts) - 1
     # hipGraph decode under TP: the all-greedy step has no backend collective inside (peer-to-peer all-reduce,
     # packed argmax exchange), is captured even with gloo ranks, replays speculatively, and reproduces the
     # eager TP=2 tokens bit for bit; fp32 models (backend all-reduce) are not captured with gloo
-    g, captured, spec_hits = run(2, "bfloat16", eager=False)
-    assert captured and spec_hits > 0 and g == a
+    g, captured, spec_hits, p2p = run(2, "bfloat16", eager=False)
+    assert g == a
+    if p2p:   # (its own start-up validation decides; test_custom_all_reduce_matches_backend covers the kernel)
+        assert captured and spec_hits > 0
     assert not run(2, "float32", eager=False)[1]
