@@ -6,13 +6,16 @@
 // ALU: with G query heads sharing a kv head the dot products are a [G x D] x [D x keys] product.
 // One workgroup (4 waves) owns one (sequence, kv head, <=16 query heads, split); each wave walks
 // 32-key tiles on v_mfma_f32_16x16x32:
-//   S^T[key][q] = K Q^T     A = K straight from HBM into the A-operand layout (16 keys x 64 B per
-//                           load instruction), B = Q^T resident in registers
+//   S^T[key][q] = K Q^T     A = K, either straight from HBM into the A-operand layout (16 keys x 64 B per
+//                           load instruction; small grids) or, KLDS, by LDS-DMA in whole 256-B rows
+//                           (swizzle on the source address) + ds_read_b128; B = Q^T resident in registers
 //   online softmax          a query head lives on lanes {q, q+16, q+32, q+48}: two shuffles per tile
 //   O^T[d][q] += V^T P^T    V is staged through a per-wave 8 KiB LDS tile (coalesced 256-B rows in,
 //                           ds_read_b64_tr_b16 transposed reads out); P^T is the S^T accumulator
 //                           reused in place (its key index is the register index)
 // No workgroup barrier in the loop: a wave only reads the LDS rows it wrote itself.
+#include <stdlib.h>
+
 #include "paged_decode.h"
 
 namespace {
@@ -30,6 +33,7 @@ constexpr int ROW_BYTES = D * 2;
 constexpr int V_TILE_BYTES = TILE * ROW_BYTES;       // 8 KiB per wave
 constexpr int MERGE_STRIDE = D + 2;                  // acc[D], m, l
 constexpr int SMEM_BYTES = NW * 16 * MERGE_STRIDE * 4;  // 33,280 B >= NW * V_TILE_BYTES
+constexpr int SMEM_BYTES_KLDS = 2 * NW * V_TILE_BYTES;  // K tile + V tile per wave: 64 KiB
 
 template <typename Tag>
 __device__ __forceinline__ f32x4 mfma16(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
@@ -58,10 +62,12 @@ __device__ __forceinline__ int v_off(int lrow, int ch) {
   return lrow * ROW_BYTES + ((ch ^ (((lrow & 3) << 2) | ((lrow >> 2) & 3))) << 4);
 }
 
-template <typename Tag>
-__global__ void __launch_bounds__(256, 4) paged_decode_mfma_kernel(DecodeParams p, int n_chunks) {
+// KLDS: K also goes through LDS (DMA in whole 256-B rows, XOR-swizzled on the source side, A operand by
+// ds_read_b128) instead of 16 rows x 64 B per load instruction straight into the A-operand registers.
+template <typename Tag, bool KLDS>
+__global__ void __launch_bounds__(256, KLDS ? 2 : 4) paged_decode_mfma_kernel(DecodeParams p, int n_chunks) {
   typedef typename elem<Tag>::T T;
-  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[KLDS ? SMEM_BYTES_KLDS : SMEM_BYTES];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, quad = lane >> 4;
@@ -99,6 +105,7 @@ __global__ void __launch_bounds__(256, 4) paged_decode_mfma_kernel(DecodeParams 
   const int32_t *table = p.block_tables + (int64_t)b * p.table_stride;
   const int64_t row_elems = (int64_t)p.n_kv_heads * D;
   char *vlds = smem + wave * V_TILE_BYTES;
+  char *klds = smem + (NW + wave) * V_TILE_BYTES;  // KLDS only
   const int q4 = i16 >> 2, pp = i16 & 3;
 
   for (int u = u_begin; u < u_end; ++u) {
@@ -117,6 +124,17 @@ __global__ void __launch_bounds__(256, 4) paged_decode_mfma_kernel(DecodeParams 
     //      fetches chunk (i16 ^ swz) of the key that lives in LDS row 4n + quad.  Keys past the context
     //      re-read the tile's first (valid) row: their probability is exactly 0 and the data is finite.
     const int n_valid = min(TILE, ctx - tile_base);
+    if constexpr (KLDS) {
+      // K first (it is needed first; vmcnt retires in order): LDS row = key, chunk XORed with (key & 15)
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        const int key = 4 * n + quad;
+        const int kk = key < n_valid ? key : 0;
+        const int ch = i16 ^ (key & 15);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb + kk * row_elems + 8 * ch),
+                                         (__attribute__((address_space(3))) void *)(klds + n * 1024), 16, 0, 2);
+      }
+    }
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
       const int lrow = 4 * n + quad;
@@ -130,14 +148,25 @@ __global__ void __launch_bounds__(256, 4) paged_decode_mfma_kernel(DecodeParams 
     }
     // ---- K: A operand, lane (key = i16, quad) reads 16 B at d = 32s + 8 quad of key 16kt + i16
     u32x4 kf[2][4];
+    if constexpr (KLDS) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 K DMAs have landed, the 8 V DMAs may still fly
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      const int kk = min(16 * kt + i16, n_valid - 1);  // past the context: re-read a valid key (masked below)
+      for (int kt = 0; kt < 2; ++kt) {
+        const int key = 16 * kt + i16;
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-        // plain loads: the four 64-B pieces of a 256-B row arrive in four instructions, the cache must
-        // keep each 128-B line until its second half is read (non-temporal K loads measured 8 % slower)
-        kf[kt][s] = *reinterpret_cast<const u32x4 *>(kb + kk * row_elems + 32 * s + 8 * quad);
+        for (int s = 0; s < 4; ++s)
+          kf[kt][s] = *reinterpret_cast<const u32x4 *>(klds + key * ROW_BYTES + (((4 * s + quad) ^ (key & 15)) << 4));
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int kk = min(16 * kt + i16, n_valid - 1);  // past the context: re-read a valid key (masked below)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          // plain loads: the four 64-B pieces of a 256-B row arrive in four instructions, the cache must
+          // keep each 128-B line until its second half is read (non-temporal K loads measured 8 % slower)
+          kf[kt][s] = *reinterpret_cast<const u32x4 *>(kb + kk * row_elems + 32 * s + 8 * quad);
+      }
     }
     // (K loads are issued AFTER the V DMA below: vmcnt retires in order, so "K has landed" implies
     //  "V is in LDS")
@@ -249,12 +278,20 @@ __global__ void __launch_bounds__(256, 4) paged_decode_mfma_kernel(DecodeParams 
 int mv_paged_decode_mfma_launch(const DecodeParams &p, int n_chunks, int nsplit, int batch, int dtype,
                                 hipStream_t stream) {
   dim3 grid(p.n_kv_heads * n_chunks, nsplit, batch), block(256);
-  if (dtype == MV_BF16)
-    hipLaunchKernelGGL((paged_decode_mfma_kernel<bf16_tag>), grid, block, 0, stream, p, n_chunks);
-  else if (dtype == MV_F16)
-    hipLaunchKernelGGL((paged_decode_mfma_kernel<f16_tag>), grid, block, 0, stream, p, n_chunks);
-  else
+  // K through LDS pays once the (sequence, kv head) pairs alone fill the chip (whole-row DMA instead of
+  // 16 rows x 64 B per load: 5.5 -> 5.9 TB/s on Qwen2-7B heads at B=256, 5.8 -> 6.4 at ctx 4096); with fewer
+  // workgroups its 2-per-CU residency (64 KiB of LDS) costs more than it gains.  MV_DECODE_MFMA_KLDS=0/1 forces.
+  static const int force = [] { const char *e = getenv("MV_DECODE_MFMA_KLDS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  const bool klds = force >= 0 ? force == 1 : (int64_t)grid.x * grid.z >= 1024;
+  if (dtype == MV_BF16) {
+    if (klds) hipLaunchKernelGGL((paged_decode_mfma_kernel<bf16_tag, true>), grid, block, 0, stream, p, n_chunks);
+    else hipLaunchKernelGGL((paged_decode_mfma_kernel<bf16_tag, false>), grid, block, 0, stream, p, n_chunks);
+  } else if (dtype == MV_F16) {
+    if (klds) hipLaunchKernelGGL((paged_decode_mfma_kernel<f16_tag, true>), grid, block, 0, stream, p, n_chunks);
+    else hipLaunchKernelGGL((paged_decode_mfma_kernel<f16_tag, false>), grid, block, 0, stream, p, n_chunks);
+  } else {
     return MV_E_DTYPE;
+  }
   MV_LAUNCH_CHECK();
   return MV_OK;
 }
