@@ -169,7 +169,10 @@ def decode_roofline(engine, args):
             for name, rec in json.load(f)["kernels"].items():
                 if args.model in name:
                     traffic = int(algo * rec["ratio"])
-    return {"bound": "hbm", "kernel": "paged_decode_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+    cfgm = MODELS[args.model]
+    kernel = ("paged_decode_mfma_kernel" if cfgm["num_attention_heads"] // cfgm["num_key_value_heads"] >= 4
+              else "paged_decode_kernel")
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_source": "profiles/r01_pmc_decode.json (PMC FETCH_SIZE x2 + WRITE_SIZE, per launch, scaled to this run's context)" if traffic else None,
             "bytes_per_launch": algo, "us_per_launch": round(sec * 1e6, 2), "launches_timed": len(kept),
