@@ -46,11 +46,15 @@ struct LinearParams {
 // (16–20 wave-wide loads in flight per wave)
 __host__ __device__ constexpr int unroll_of(int rpw, int mt) { return rpw + mt <= 2 ? 8 : (rpw + mt <= 5 ? 4 : 2); }
 
-template <typename Tag, int RPW, int MT, bool GATED>
+// XLDS: the x block of a wave (MT·16 rows x kUnroll·32 elements) comes in by LDS-DMA in whole-row pieces
+// (2-4 rows x 256-512 B per instruction, XOR swizzle applied on the source address) and the B fragments are
+// ds_read_b128 -- instead of 16 rows x 64 B per load instruction straight into the B-operand registers, which
+// costs the texture path as much as the weight fragments do.  Chosen by run() where it measured faster.
+template <typename Tag, int RPW, int MT, bool GATED, bool XLDS>
 __global__ void __launch_bounds__((GATED ? 2 : 1) * RPW * MT >= 12 ? 512 : 1024)
 linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of partial-tile LDS allow <= 5 waves)
   typedef uint16_t T;
-  extern __shared__ float red[];  // [waves][RPW*MT][64][4]
+  extern __shared__ float red[];  // [waves][RPW*MT][64][4]; XLDS: first the per-wave x blocks
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * (RPW * 16);
@@ -84,6 +88,10 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
   // blocks of kUnroll k-steps, all loads of a block issued before its first MFMA; the last block of a
   // slice is shifted back to end at the slice's end and feeds zeros for the steps already done (no
   // serial tail; the host guarantees K/32 >= kUnroll so the shifted window stays inside the row)
+  constexpr int RB = kUnroll * 64;             // bytes of one x row in a block
+  constexpr int XBLOCK = MT * 16 * RB;         // bytes of a wave's x block
+  constexpr int XM = (RB / 16 - 1) & 15;       // swizzle mask: stays inside the row's chunks
+  char *xl = (char *)red + wave * XBLOCK;      // XLDS
   for (int s = s_lo; s < s_hi; s += kUnroll) {
     int sb = s + kUnroll <= s_hi ? s : s_hi - kUnroll;
     sb = sb < 0 ? 0 : sb;
@@ -92,8 +100,32 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
     for (int u = 0; u < kUnroll; ++u) {
 #pragma unroll
       for (int a = 0; a < NA; ++a) wf[u][a] = *(const u32x4 *)(wp[a] + sb * 32 + u * 32);
+      if constexpr (!XLDS) {
 #pragma unroll
-      for (int b = 0; b < MT; ++b) xf[u][b] = *(const u32x4 *)(xp[b] + sb * 32 + u * 32);
+        for (int b = 0; b < MT; ++b) xf[u][b] = *(const u32x4 *)(xp[b] + sb * 32 + u * 32);
+      }
+    }
+    if constexpr (XLDS) {
+      // instruction n fills LDS bytes [1024 n, 1024 (n+1)) of the block linearly: lane -> (row, stored chunk);
+      // it fetches the LOGICAL chunk (stored ^ (row & 15)) of that row, so that the B-fragment reads below
+      // (16 rows, one logical chunk) hit 16 different bank groups
+#pragma unroll
+      for (int n = 0; n < XBLOCK / 1024; ++n) {
+        const int o = n * 1024 + lane * 16;
+        const int row = o / RB, pc = (o % RB) >> 4;
+        const int m = row < p.M ? row : p.M - 1;
+        const T *src = (const T *)p.x + (int64_t)m * p.x_stride + sb * 32 + ((pc ^ (row & XM)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(xl + n * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA is invisible to the compiler's own counting
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+          const int row = b * 16 + r16;
+          xf[u][b] = *(const u32x4 *)(xl + row * RB + (((4 * u + g) ^ (row & XM)) << 4));
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -112,6 +144,7 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
   // partial tiles -> LDS, then output tile t of the workgroup is finished by wave t % nwaves
   constexpr int NT = NA * MT;
   f32x4 *red4 = (f32x4 *)red;
+  if constexpr (XLDS) __syncthreads();  // the partial tiles overwrite the x blocks of other waves
 #pragma unroll
   for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -156,24 +189,24 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
   }
 }
 
-template <typename Tag, int RPW, bool GATED>
+template <typename Tag, int RPW, bool GATED, bool XLDS>
 int launch_mt_(const LinearParams &p, int mt, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
   switch (mt) {
-    case 1: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 1, GATED>), grid, block, lds, stream, p); break;
-    case 2: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 2, GATED>), grid, block, lds, stream, p); break;
-    case 3: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 3, GATED>), grid, block, lds, stream, p); break;
-    default: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 4, GATED>), grid, block, lds, stream, p); break;
+    case 1: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 1, GATED, XLDS>), grid, block, lds, stream, p); break;
+    case 2: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 2, GATED, XLDS>), grid, block, lds, stream, p); break;
+    case 3: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 3, GATED, XLDS>), grid, block, lds, stream, p); break;
+    default: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 4, GATED, XLDS>), grid, block, lds, stream, p); break;
   }
   MV_LAUNCH_CHECK();
   return MV_OK;
 }
 
-template <typename Tag, bool GATED>
+template <typename Tag, bool GATED, bool XLDS>
 int launch(const LinearParams &p, int rpw, int mt, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
   if constexpr (!GATED)
-    if (rpw == 4) return launch_mt_<Tag, 4, GATED>(p, mt, grid, block, lds, stream);
-  if (rpw == 2) return launch_mt_<Tag, 2, GATED>(p, mt, grid, block, lds, stream);
-  return launch_mt_<Tag, 1, GATED>(p, mt, grid, block, lds, stream);
+    if (rpw == 4) return launch_mt_<Tag, 4, GATED, XLDS>(p, mt, grid, block, lds, stream);
+  if (rpw == 2) return launch_mt_<Tag, 2, GATED, XLDS>(p, mt, grid, block, lds, stream);
+  return launch_mt_<Tag, 1, GATED, XLDS>(p, mt, grid, block, lds, stream);
 }
 
 // MV_LINEAR_RPW / MV_LINEAR_WAVES override the launch shape, for tools/bench_linear.py --sweep only: they are
@@ -207,10 +240,21 @@ int run(const LinearParams &p, int dtype, hipStream_t st) {
   const int force_waves = env_int("MV_LINEAR_WAVES");
   if (force_waves >= 1 && force_waves <= 16 && force_waves * na * mt <= 64) waves = force_waves;
   while (waves > 1 && waves * na * mt > 64) waves /= 2;  // 64 KB of LDS for the partial tiles
-  const size_t lds = (size_t)waves * na * mt * 64 * sizeof(f32x4);
+  // x through LDS once its fragment-shaped loads weigh: from 12 rows up, unless 4 row tiles per wave already
+  // amortise them (measured, tools/dbg/xlds_bench.sh: M=16 +5..17 % on the 8-34 MB layers, -15 % on the LM
+  // head with RPW 4; M=32 +7..30 % everywhere; M <= 8 -1..-10 %)
+  const int force_xlds = env_int("MV_LINEAR_XLDS");
+  const bool xlds = force_xlds ? force_xlds > 0 : (mt >= 2 || (m >= 12 && rpw < 4));
+  const size_t xblock = (size_t)mt * 16 * unroll * 64;
+  while (xlds && waves > 1 && waves * xblock > 65536) waves /= 2;
+  size_t lds = (size_t)waves * na * mt * 64 * sizeof(f32x4);
+  if (xlds && waves * xblock > lds) lds = waves * xblock;
   dim3 grid(tiles), block(waves * 64);
-  return dtype == MV_BF16 ? launch<bf16_tag, GATED>(p, rpw, mt, grid, block, lds, st)
-                          : launch<f16_tag, GATED>(p, rpw, mt, grid, block, lds, st);
+  if (xlds)
+    return dtype == MV_BF16 ? launch<bf16_tag, GATED, true>(p, rpw, mt, grid, block, lds, st)
+                            : launch<f16_tag, GATED, true>(p, rpw, mt, grid, block, lds, st);
+  return dtype == MV_BF16 ? launch<bf16_tag, GATED, false>(p, rpw, mt, grid, block, lds, st)
+                          : launch<f16_tag, GATED, false>(p, rpw, mt, grid, block, lds, st);
 }
 
 int check(const void *x, int64_t x_stride, const void *w, const void *bias, void *out, int64_t out_stride, int m,
