@@ -34,9 +34,13 @@ __all__ = ["InferenceExecutor", "graph_batch_sizes", "kv_block_bytes"]
 
 def graph_batch_sizes(max_batch_size: int) -> list[int]:
     """Decode graph buckets: 1,2,4,8,12 then every 16 up to min(max, 512)
-    (inference_executor.py:839-841)."""
-    sizes = [1, 2, 4, 8, 12] + list(range(16, min(max_batch_size, 512) + 1, 16))
-    return [s for s in sizes if s <= max(max_batch_size, 1)] or [1]
+    (inference_executor.py:839-841) -- plus the maximum itself when it is not on that grid (the reference's
+    list leaves batches between the last multiple of 16 and max_num_seqs without a graph)."""
+    top = min(max(max_batch_size, 1), 512)
+    sizes = [s for s in [1, 2, 4, 8, 12] + list(range(16, top + 1, 16)) if s <= top]
+    if sizes[-1] != top:
+        sizes.append(top)
+    return sizes
 
 
 def kv_block_bytes(num_layers: int, block_size: int, num_kv_heads_local: int, head_dim: int, itemsize: int) -> int:

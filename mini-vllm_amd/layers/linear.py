@@ -23,7 +23,19 @@ SMALL_M_MAX = int(os.environ.get("MV_LINEAR_SMALL_M_MAX", "16"))
 
 
 def small_m(x, weight) -> bool:
-    return (x.is_cuda and 0 < x.numel() // x.shape[-1] <= SMALL_M_MAX and hip_ops.linear_small_m_ok(x, weight))
+    """Does this projection go to the weight-streaming kernel?  Up to SMALL_M_MAX rows always; up to twice that
+    for the shapes where it still measured faster than hipBLASLt (tools/dbg/xlds_bench.sh, M = 32): the small
+    layers (qkv / o of Qwen3-1.7B: 8.3 / 7.2 vs 11.8 / 11.2 us), the LM head (123 vs 149 us) and very deep K
+    (Qwen2-7B down: 48 vs 108 us) -- not the 25-270 MB gate_up matrices."""
+    if not x.is_cuda:
+        return False
+    rows = x.numel() // x.shape[-1]
+    if not 0 < rows <= 2 * SMALL_M_MAX or not hip_ops.linear_small_m_ok(x, weight):
+        return False
+    if rows <= SMALL_M_MAX:
+        return True
+    n, k = weight.shape
+    return n * k <= 10_000_000 or n >= 65536 or k >= 16384
 
 
 def linear(x, weight, bias=None):

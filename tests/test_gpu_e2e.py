@@ -346,6 +346,8 @@ def test_kv_cache_auto_sizing_and_graph_buckets(golden_dir, tmp_path):
     assert att.k_cache.data_ptr() == ex.kv_cache[0, 1].data_ptr() and att.v_cache.data_ptr() == ex.kv_cache[1, 1].data_ptr()
     assert graph_batch_sizes(256) == [1, 2, 4, 8, 12] + list(range(16, 257, 16))
     assert graph_batch_sizes(8) == [1, 2, 4, 8] and graph_batch_sizes(1000)[-1] == 512
+    assert graph_batch_sizes(24) == [1, 2, 4, 8, 12, 16, 24] and graph_batch_sizes(3) == [1, 2, 3]
+    assert graph_batch_sizes(1) == [1]
 
 
 def test_randomized_serving_speculation_changes_nothing(golden_dir, tmp_path, monkeypatch):
