@@ -50,7 +50,8 @@ __host__ __device__ constexpr int unroll_of(int rpw, int mt) { return rpw + mt <
 // (2-4 rows x 256-512 B per instruction, XOR swizzle applied on the source address) and the B fragments are
 // ds_read_b128 -- instead of 16 rows x 64 B per load instruction straight into the B-operand registers, which
 // costs the texture path as much as the weight fragments do.  Chosen by run() where it measured faster.
-template <typename Tag, int RPW, int MT, bool GATED, bool XLDS>
+// WLDS: the same for the weight block of a wave that owns one 16-row tile (x then stays in registers).
+template <typename Tag, int RPW, int MT, bool GATED, bool XLDS, bool WLDS = false>
 __global__ void __launch_bounds__((GATED ? 2 : 1) * RPW * MT >= 12 ? 512 : 1024)
 linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of partial-tile LDS allow <= 5 waves)
   typedef uint16_t T;
@@ -96,10 +97,26 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
     int sb = s + kUnroll <= s_hi ? s : s_hi - kUnroll;
     sb = sb < 0 ? 0 : sb;
     u32x4 wf[kUnroll][NA], xf[kUnroll][MT];
+    if constexpr (WLDS) {
+      static_assert(!WLDS || (!XLDS && NA == 1), "W through LDS: one weight tile per wave, x straight to registers");
+      // weight block: 16 rows x RB bytes by whole-row DMA (swizzled on the source), A fragments by ds_read_b128
+#pragma unroll
+      for (int n = 0; n < (16 * RB) / 1024; ++n) {
+        const int o = n * 1024 + lane * 16;
+        const int row = o / RB, pc = (o % RB) >> 4;
+        int nrow = n0 + row;
+        nrow = nrow < p.N ? nrow : p.N - 1;
+        const T *src = (const T *)p.w + (int64_t)nrow * p.K + sb * 32 + ((pc ^ (row & XM)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(xl + n * 1024), 16, 0, 0);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
+      if constexpr (!WLDS) {
 #pragma unroll
-      for (int a = 0; a < NA; ++a) wf[u][a] = *(const u32x4 *)(wp[a] + sb * 32 + u * 32);
+        for (int a = 0; a < NA; ++a) wf[u][a] = *(const u32x4 *)(wp[a] + sb * 32 + u * 32);
+      }
       if constexpr (!XLDS) {
 #pragma unroll
         for (int b = 0; b < MT; ++b) xf[u][b] = *(const u32x4 *)(xp[b] + sb * 32 + u * 32);
@@ -127,6 +144,12 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
           xf[u][b] = *(const u32x4 *)(xl + row * RB + (((4 * u + g) ^ (row & XM)) << 4));
         }
     }
+    if constexpr (WLDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u)
+        wf[u][0] = *(const u32x4 *)(xl + r16 * RB + (((4 * u + g) ^ (r16 & XM)) << 4));
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
@@ -144,7 +167,7 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
   // partial tiles -> LDS, then output tile t of the workgroup is finished by wave t % nwaves
   constexpr int NT = NA * MT;
   f32x4 *red4 = (f32x4 *)red;
-  if constexpr (XLDS) __syncthreads();  // the partial tiles overwrite the x blocks of other waves
+  if constexpr (XLDS || WLDS) __syncthreads();  // the partial tiles overwrite the blocks of other waves
 #pragma unroll
   for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -250,6 +273,22 @@ int run(const LinearParams &p, int dtype, hipStream_t st) {
   size_t lds = (size_t)waves * na * mt * 64 * sizeof(f32x4);
   if (xlds && waves * xblock > lds) lds = waves * xblock;
   dim3 grid(tiles), block(waves * 64);
+  // one weight tile per wave and more than one block per K slice (K >= 3584, or 6144 over 8 waves): the
+  // weight block also comes in by whole-row DMA (+13..25 % on the down / Qwen2-7B qkv projections at M <= 8,
+  // -5 % on single-block slices and on the LM head, tools/dbg/wlds_bench.sh); MV_LINEAR_WLDS=1/-1 forces
+  const int force_wlds = env_int("MV_LINEAR_WLDS");
+  const bool wlds = force_wlds ? force_wlds > 0 : (steps / waves > unroll && n < 65536);
+  if (wlds && !xlds && !GATED && rpw == 1 && mt == 1) {
+    while (waves > 1 && waves * xblock > 65536) waves /= 2;
+    if (waves * xblock > lds) lds = waves * xblock;
+    dim3 blk(waves * 64);
+    if (dtype == MV_BF16)
+      hipLaunchKernelGGL((linear_small_m_kernel<bf16_tag, 1, 1, false, false, true>), grid, blk, lds, st, p);
+    else
+      hipLaunchKernelGGL((linear_small_m_kernel<f16_tag, 1, 1, false, false, true>), grid, blk, lds, st, p);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+  }
   if (xlds)
     return dtype == MV_BF16 ? launch<bf16_tag, GATED, true>(p, rpw, mt, grid, block, lds, st)
                             : launch<f16_tag, GATED, true>(p, rpw, mt, grid, block, lds, st);
