@@ -90,7 +90,7 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
   // slice is shifted back to end at the slice's end and feeds zeros for the steps already done (no
   // serial tail; the host guarantees K/32 >= kUnroll so the shifted window stays inside the row)
   constexpr int RB = kUnroll * 64;             // bytes of one x row in a block
-  constexpr int XBLOCK = MT * 16 * RB;         // bytes of a wave's x block
+  constexpr int XBLOCK = (WLDS ? NA : MT) * 16 * RB;  // bytes of a wave's x (XLDS) or weight (WLDS) block
   constexpr int XM = (RB / 16 - 1) & 15;       // swizzle mask: stays inside the row's chunks
   char *xl = (char *)red + wave * XBLOCK;      // XLDS
   for (int s = s_lo; s < s_hi; s += kUnroll) {
@@ -98,14 +98,17 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
     sb = sb < 0 ? 0 : sb;
     u32x4 wf[kUnroll][NA], xf[kUnroll][MT];
     if constexpr (WLDS) {
-      static_assert(!WLDS || (!XLDS && NA == 1), "W through LDS: one weight tile per wave, x straight to registers");
-      // weight block: 16 rows x RB bytes by whole-row DMA (swizzled on the source), A fragments by ds_read_b128
+      static_assert(!WLDS || !XLDS, "W through LDS: x goes straight to registers");
+      // weight block: NA tiles x 16 rows x RB bytes by whole-row DMA (swizzled on the source), A fragments by
+      // ds_read_b128
 #pragma unroll
-      for (int n = 0; n < (16 * RB) / 1024; ++n) {
+      for (int n = 0; n < (NA * 16 * RB) / 1024; ++n) {
         const int o = n * 1024 + lane * 16;
-        const int row = o / RB, pc = (o % RB) >> 4;
-        int nrow = n0 + row;
+        const int trow = o / RB, pc = (o % RB) >> 4;   // trow = tile * 16 + row
+        const int a = trow >> 4, row = trow & 15;
+        int nrow = n0 + (a % RPW) * 16 + row;
         nrow = nrow < p.N ? nrow : p.N - 1;
+        if (GATED && a >= RPW) nrow += p.N;
         const T *src = (const T *)p.w + (int64_t)nrow * p.K + sb * 32 + ((pc ^ (row & XM)) << 3);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(xl + n * 1024), 16, 0, 0);
@@ -148,7 +151,9 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u)
-        wf[u][0] = *(const u32x4 *)(xl + r16 * RB + (((4 * u + g) ^ (r16 & XM)) << 4));
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+          wf[u][a] = *(const u32x4 *)(xl + (a * 16 + r16) * RB + (((4 * u + g) ^ (r16 & XM)) << 4));
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -273,21 +278,35 @@ int run(const LinearParams &p, int dtype, hipStream_t st) {
   size_t lds = (size_t)waves * na * mt * 64 * sizeof(f32x4);
   if (xlds && waves * xblock > lds) lds = waves * xblock;
   dim3 grid(tiles), block(waves * 64);
-  // one weight tile per wave and more than one block per K slice (K >= 3584, or 6144 over 8 waves): the
+  // one or two weight tiles per wave and more than one block per K slice (K >= 3584, or 6144 over 8 waves): the
   // weight block also comes in by whole-row DMA (+13..25 % on the down / Qwen2-7B qkv projections at M <= 8,
   // -5 % on single-block slices and on the LM head, tools/dbg/wlds_bench.sh); MV_LINEAR_WLDS=1/-1 forces
   const int force_wlds = env_int("MV_LINEAR_WLDS");
   const bool wlds = force_wlds ? force_wlds > 0 : (steps / waves > unroll && n < 65536);
-  if (wlds && !xlds && !GATED && rpw == 1 && mt == 1) {
-    while (waves > 1 && waves * xblock > 65536) waves /= 2;
-    if (waves * xblock > lds) lds = waves * xblock;
+  if (wlds && !xlds && mt == 1 && na <= 2) {
+    const size_t wblock = (size_t)na * 16 * unroll * 64;
+    while (waves > 1 && waves * wblock > 65536) waves /= 2;
+    if (waves * wblock > lds) lds = waves * wblock;
     dim3 blk(waves * 64);
-    if (dtype == MV_BF16)
-      hipLaunchKernelGGL((linear_small_m_kernel<bf16_tag, 1, 1, false, false, true>), grid, blk, lds, st, p);
-    else
-      hipLaunchKernelGGL((linear_small_m_kernel<f16_tag, 1, 1, false, false, true>), grid, blk, lds, st, p);
-    MV_LAUNCH_CHECK();
-    return MV_OK;
+#define MV_WLDS(TAG)                                                                                             \
+  do {                                                                                                           \
+    if (rpw == 2) hipLaunchKernelGGL((linear_small_m_kernel<TAG, 2, 1, GATED, false, true>), grid, blk, lds, st, p); \
+    else hipLaunchKernelGGL((linear_small_m_kernel<TAG, 1, 1, GATED, false, true>), grid, blk, lds, st, p);      \
+  } while (0)
+    if constexpr (GATED) {
+      if (rpw == 1) {
+        if (dtype == MV_BF16) hipLaunchKernelGGL((linear_small_m_kernel<bf16_tag, 1, 1, true, false, true>), grid, blk, lds, st, p);
+        else hipLaunchKernelGGL((linear_small_m_kernel<f16_tag, 1, 1, true, false, true>), grid, blk, lds, st, p);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+      }
+    } else {
+      if (dtype == MV_BF16) MV_WLDS(bf16_tag);
+      else MV_WLDS(f16_tag);
+      MV_LAUNCH_CHECK();
+      return MV_OK;
+    }
+#undef MV_WLDS
   }
   if (xlds)
     return dtype == MV_BF16 ? launch<bf16_tag, GATED, true>(p, rpw, mt, grid, block, lds, st)
