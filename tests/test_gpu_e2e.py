@@ -27,7 +27,7 @@ def _build(tmp_path, z, dtype, enforce_eager=True, max_num_seqs=8):
     (d / "config.json").write_text(bytes(z["config_json"]).decode())
     cfg = Config(str(d), num_kvcache_blocks=16, kvcache_block_size=64, max_model_len=512,
                  max_num_batched_tokens=1024, max_num_seqs=max_num_seqs, enforce_eager=enforce_eager,
-                 dtype="float32" if dtype == torch.float32 else "bfloat16")
+                 dtype={torch.float32: "float32", torch.float16: "float16"}.get(dtype, "bfloat16"))
     prev = torch.get_default_dtype()
     torch.set_default_dtype(dtype)
     try:
@@ -110,6 +110,22 @@ def test_bf16_logits_within_reference_noise(golden_dir, tmp_path, name):
         err = (got - want32).abs().max().item()
         assert err <= max(1e-3 * scale, 1.5 * ref_noise), f"{name} step {i}: err {err:.3e} noise {ref_noise:.3e}"
         # greedy token identical wherever the fp32 top-2 margin exceeds the error
+        top2 = want32.topk(2, dim=-1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 2 * err
+        assert torch.equal(torch.tensor(toks)[safe], want32.argmax(-1)[safe])
+
+
+@pytest.mark.parametrize("name", ["qwen3", "qwen2"])
+def test_f16_logits_close_to_reference_fp32(golden_dir, tmp_path, name):
+    """float16 end to end (the third dtype of the C-ABI): every kernel in its f16 instantiation.  f16 carries
+    3 more mantissa bits than bf16, so the logits must sit inside the bf16 bound of the test above."""
+    z = _load(golden_dir, name)
+    _, _, ex = _build(tmp_path, z, torch.float16)
+    outs = _run(ex, z)
+    for i, ((got, toks), want32, want16) in enumerate(zip(outs, _ref(z, "f32"), _ref(z, "bf16"))):
+        scale = want32.abs().max().item()
+        err = (got - want32).abs().max().item()
+        assert err <= max(1e-3 * scale, 1.5 * (want16 - want32).abs().max().item()), f"{name} step {i}: err {err:.3e}"
         top2 = want32.topk(2, dim=-1).values
         safe = (top2[:, 0] - top2[:, 1]) > 2 * err
         assert torch.equal(torch.tensor(toks)[safe], want32.argmax(-1)[safe])
