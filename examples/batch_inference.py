@@ -3,7 +3,7 @@
 examples/batch_inference_example.py): ``LLM(Config(...)).generate(prompts, SamplingParams(...))``.
 
     python examples/batch_inference.py /path/to/Qwen3-1.7B --max-tokens 64
-    python examples/batch_inference.py /path/to/model_dir --dummy          # random weights, token-id prompts
+    python examples/batch_inference.py examples/qwen3-0.6b --dummy         # random weights (config.json only), token-id prompts
 """
 import argparse
 import os

@@ -132,6 +132,14 @@ class LLMEngine:
         if self._is_driver:
             if self.tokenizer is not None:   # ship token ids: workers need no tokenizer round trip
                 prompts = [self.tokenizer.encode(p) if isinstance(p, str) else p for p in prompts]
+            # whatever would make a rank raise half-way through must fail HERE, before the workers are told
+            if isinstance(sampling_params, list) and len(sampling_params) != len(prompts):
+                raise ValueError("Length of sampling_params list must match prompts")
+            for p in prompts:
+                if isinstance(p, str):
+                    raise RuntimeError("no tokenizer loaded: pass prompts as lists of token ids")
+                if not p:
+                    raise ValueError("token_ids must contain at least one token")
             self.model_runner.distributed_manager.broadcast_data(("generate", prompts, sampling_params), src=0)
         return self._generate_local(prompts, sampling_params, use_tqdm)
 

@@ -59,6 +59,12 @@ class ModelManager:
         from transformers import AutoTokenizer
 
         try:
+            # a directory without vocabulary files still yields a tokenizer OBJECT (one special token, every
+            # string encodes to []): insist on the files
+            files = ("tokenizer.json", "tokenizer.model", "vocab.json", "tokenizer_config.json")
+            if os.path.isdir(self.config.model) and not any(
+                    os.path.exists(os.path.join(self.config.model, f)) for f in files):
+                raise FileNotFoundError(f"no tokenizer files in {self.config.model}")
             tok = AutoTokenizer.from_pretrained(self.config.model, trust_remote_code=True, use_fast=True,
                                                 local_files_only=True)
             if tok.pad_token is None:
