@@ -83,9 +83,12 @@ class LLMEngine:
         if runner is None:
             return
         try:
-            if self._is_driver:
+            # a dead worker can no longer take part in a collective: do not block the exit on it
+            workers_alive = all(p.is_alive() for p in self.ps)
+            if self._is_driver and workers_alive:
                 runner.distributed_manager.broadcast_data(("exit",), src=0)
-            runner.call("exit")
+            if workers_alive or not self._is_driver:
+                runner.call("exit")
         except Exception as e:
             warnings.warn(f"Errors during engine cleanup: {e}", RuntimeWarning, stacklevel=2)
         for i, p in enumerate(self.ps):
