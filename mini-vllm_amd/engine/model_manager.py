@@ -71,9 +71,9 @@ class ModelManager:
                 tok.pad_token = tok.eos_token
             self.tokenizer = tok
         except Exception as e:
-            if self.config.load_format != "dummy":
-                raise RuntimeError(f"Failed to load tokenizer: {e}") from e
-            logger.warning("no tokenizer in %s: prompts must be token-id lists", self.config.model)
+            # the reference refuses to start without a tokenizer (models/manager.py:111-117); here a model
+            # directory without one still serves token-id prompts (string prompts then raise in add_request)
+            logger.warning("no usable tokenizer in %s (%s): prompts must be token-id lists", self.config.model, e)
             self.tokenizer = None
 
     def _load_model(self) -> None:
