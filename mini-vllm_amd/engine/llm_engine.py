@@ -143,6 +143,9 @@ class LLMEngine:
                     raise RuntimeError("no tokenizer loaded: pass prompts as lists of token ids")
                 if not p:
                     raise ValueError("token_ids must contain at least one token")
+                if len(p) > min(self.config.max_num_batched_tokens, self.config.max_model_len):
+                    # (single process: the scheduler raises "No sequences scheduled" for it, like the reference)
+                    raise ValueError(f"prompt of {len(p)} tokens exceeds max_num_batched_tokens / max_model_len")
             self.model_runner.distributed_manager.broadcast_data(("generate", prompts, sampling_params), src=0)
         return self._generate_local(prompts, sampling_params, use_tqdm)
 
