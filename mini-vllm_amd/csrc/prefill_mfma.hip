@@ -3,8 +3,8 @@
 //  semantics of the fallback :467-504,554-597 with bottom-right aligned causal mask).
 //
 // One workgroup = 4 waves = 128 query rows of one (sequence, query head); each wave owns 32
-// rows.  K/V are streamed in 64-key tiles through LDS (next tile's global loads are issued
-// before the current tile's MFMAs and written to LDS after the barrier).
+// rows.  K/V are streamed in 64-key tiles through LDS, double-buffered, by LDS-DMA (the next tile's
+// transfers are issued before the current tile's MFMAs and waited for right before the tile's barrier).
 // Per wave and tile, all on v_mfma_f32_32x32x16:
 //   S^T[key][q] = K Q^T      A = K rows from LDS (ds_read_b128, XOR-swizzled), B = Q^T in registers
 //   online softmax           a query row lives on lane r and lane r+32 (16 keys each per 32-key tile):
@@ -110,23 +110,21 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
   const int n_tiles = (kv_len + BN - 1) / BN;
   const int wave_qpos_min = shift + qb * BM + wave * 32;  // smallest key limit among this wave's rows
 
-  // ---- tile staging: each thread moves 4 x 16 B of K and of V per tile.  Loads are unconditional
-  //      (a predicated load becomes an exec-masked branch per load): rows past the sequence end
-  //      re-read the last valid key — finite data whose probability is exactly 0 after masking.
   const bool paged = p.block_tables != nullptr;
   const T *ksrc = paged ? (const T *)p.k_cache : (const T *)p.k;
   const T *vsrc = paged ? (const T *)p.v_cache : (const T *)p.v;
   const int64_t kstride = paged ? (int64_t)p.n_kv_heads * D : p.k_stride;
   const int64_t vstride = paged ? (int64_t)p.n_kv_heads * D : p.v_stride;
-  u32x4 kreg[4], vreg[4];
+  // ---- tile staging: K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4), no VGPR staging and no
+  //      ds_write pass (+3..15 % over register staging).  The DMA of tile t+1 is issued at the top of iteration
+  //      t into the buffer whose readers all passed the previous barrier.  A DMA instruction fills 1 KiB of LDS
+  //      linearly per wave (4 rows x 256 B), so both swizzles go on the SOURCE address: lane -> (row, stored
+  //      chunk) fetches the logical chunk that belongs there.  Rows past the sequence end re-read the last valid
+  //      key (finite data whose probability is exactly 0 after masking); loads are unconditional.
   bool tile_ok_next = true;
-  // thread (row tid/16, chunk tid%16) + 16 rows per i: the per-thread byte offset is loop invariant, the
-  // tile base and the 16-row steps are wave-uniform (scalar registers)
-  const uint32_t thr_k = (uint32_t)(((tid >> 4) * kstride + (tid & 15) * 8) * 2);
-  const uint32_t thr_v = (uint32_t)(((tid >> 4) * vstride + (tid & 15) * 8) * 2);
-  auto fetch = [&](int t) {
+  auto dma = [&](int t, int buf) {
     const int kv0 = t * BN;
-    int64_t base_row = k0 + kv0;  // row index into the K/V source of key kv0
+    int64_t base_row = k0 + kv0;
     tile_ok_next = true;
     if (paged) {
       const int bi = kv0 / p.block_size;
@@ -134,33 +132,22 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
       tile_ok_next = blk >= 0 && blk < p.num_blocks;  // a hole: read block 0, mask the whole tile
       base_row = (int64_t)(tile_ok_next ? blk : 0) * p.block_size + (kv0 - bi * p.block_size);
     }
-    const char *kt = (const char *)(ksrc + base_row * kstride + hkv * D);
-    const char *vt = (const char *)(vsrc + base_row * vstride + hkv * D);
-    const int last = sk - 1 - kv0;  // last valid row of this tile (>= 0: the tile starts inside the sequence)
-    if (last >= BN - 1) {           // full tile (all but the last one): no per-row clamp, no address math
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        kreg[i] = *reinterpret_cast<const u32x4 *>(kt + (int64_t)i * 32 * kstride + thr_k);
-        vreg[i] = *reinterpret_cast<const u32x4 *>(vt + (int64_t)i * 32 * vstride + thr_v);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int pc = tid + 256 * i;
-        const int row = min(pc >> 4, last), ch = pc & 15;
-        kreg[i] = *reinterpret_cast<const u32x4 *>(kt + ((int64_t)row * kstride + ch * 8) * 2);
-        vreg[i] = *reinterpret_cast<const u32x4 *>(vt + ((int64_t)row * vstride + ch * 8) * 2);
-      }
-    }
-  };
-  auto stage = [&](int buf) {
+    const T *kt = ksrc + base_row * kstride + hkv * D;
+    const T *vt = vsrc + base_row * vstride + hkv * D;
+    const int last = sk - 1 - kv0;
     char *dk = smem + buf * 2 * TILE_BYTES, *dv = dk + TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int pc = tid + 256 * i;
-      const int row = pc >> 4, ch = pc & 15;
-      *reinterpret_cast<u32x4 *>(dk + k_off(row, ch)) = kreg[i];
-      *reinterpret_cast<u32x4 *>(dv + v_off(row, ch)) = vreg[i];
+      // wave `wave`, instruction i fill LDS rows 4 (4 i + wave) .. +3 linearly: lane -> (row, stored chunk)
+      const int wv = wave;
+      const int row = 4 * (4 * i + wv) + (lane >> 4), pc = lane & 15;
+      const int srow = min(row, last);
+      const int kch = pc ^ (row & 15);
+      const int vch = pc ^ (((row & 3) << 2) | ((row >> 2) & 3));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kt + (int64_t)srow * kstride + kch * 8),
+                                       (__attribute__((address_space(3))) void *)(dk + (4 * i + wv) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vt + (int64_t)srow * vstride + vch * 8),
+                                       (__attribute__((address_space(3))) void *)(dv + (4 * i + wv) * 1024), 16, 0, 0);
     }
   };
 
@@ -181,16 +168,16 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
 
   bool tile_ok = true;
   if (n_tiles > 0) {
-    fetch(0);
+    dma(0, 0);
     tile_ok = tile_ok_next;
-    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler does not count LDS-DMA completions)
   }
   __syncthreads();
   for (int t = 0; t < n_tiles; ++t) {
     ldsK = smem + (t & 1) * 2 * TILE_BYTES;
     ldsV = ldsK + TILE_BYTES;
     const bool have_next = t + 1 < n_tiles;
-    if (have_next) fetch(t + 1);  // global -> registers, in flight during this tile's MFMAs
+    if (have_next) dma(t + 1, (t + 1) & 1);  // global -> the other LDS buffer, in flight during this tile's MFMAs
     const int kv0 = t * BN;
 
     // ---- S^T = K Q^T : two 32-key tiles (raw, unscaled scores; first k-step starts from an inline 0)
@@ -284,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
       }
     // registers -> the OTHER buffer (last read one iteration ago, behind the previous barrier), then the
     // single barrier of this tile: publishes tile t+1 and retires every wave's reads of tile t
-    if (have_next) stage((t + 1) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile t+1 has landed
     tile_ok = tile_ok_next;
     __syncthreads();
   }
