@@ -195,7 +195,7 @@ class InferenceExecutor:
             return torch.empty(0, device=self.device), []
         try:
             if prefill:
-                self._spec = None  # a speculative decode step in flight (if any) is simply ignored
+                self._drop_speculation()  # a speculative decode step in flight (if any) is simply ignored
                 inp = self.builder.prefill(sequences)
                 ids, pos = self._ship_prefill(inp, sequences)
                 greedy = self._tp_greedy(sequences)
@@ -207,6 +207,7 @@ class InferenceExecutor:
                 if bs is not None and inp.packed:
                     logits, tokens = self._replay_graph(bs, inp, sequences)
                 else:
+                    self._drop_speculation()
                     ids, pos = self._ship_decode(inp)
                     greedy = self._tp_greedy(sequences)
                     logits = self.model.compute_logits(self.model(ids, pos), gather=not greedy)
@@ -305,7 +306,7 @@ class InferenceExecutor:
             return None
         greedy = bool(self.greedy_graphs) and self._tp_greedy(sequences)
         if not greedy and self._general_capture == "lazy":
-            self._spec = None
+            self._drop_speculation()
             torch.cuda.synchronize(self.device)
             self._capture_general()
         family = self.greedy_graphs if greedy else self.graphs
@@ -349,7 +350,6 @@ class InferenceExecutor:
         hip_ops.workspace(max(hip_ops.paged_decode_workspace_bytes(bs, heads, self.num_kv_heads, self.head_dim,
                                                                    self.block_size, self.max_blocks_per_seq)
                               for bs in self.graph_bs), dev)
-        self.sampler.offset_dev = gv["rng_offset"]
         self._general_capture = "no" if not general_ok else "done"
         try:
             if self.tp_size > 1:   # the family without a backend collective inside (peer-to-peer kernels only)
@@ -368,7 +368,6 @@ class InferenceExecutor:
             self.graphs.clear()
             self.greedy_graphs.clear()
             self.graph_pool = None
-            self.sampler.offset_dev = None
             self._general_capture = "no"
             self._recover_from_failed_capture()
 
@@ -452,7 +451,7 @@ class InferenceExecutor:
         gv = self.graph_vars
         greedy = bool(self.greedy_graphs) and self._tp_greedy(sequences)
         graph = self.greedy_graphs[bs] if greedy else self.graphs[bs]
-        spec, self._spec = self._spec, None
+        spec = self._spec
         hit = False
         if spec is not None:
             batch, sbs, lens, slot, sgraph = spec
@@ -462,6 +461,10 @@ class InferenceExecutor:
                    and all(s.num_tokens == n for s, n in zip(sequences, lens)))
             self.spec_hits += hit
             self.spec_misses += not hit
+            if hit:
+                self._spec = None
+            else:
+                self._drop_speculation()
         if hit:
             slot_now = slot  # this step is already executing (or done): its tokens land in that slot
         else:
@@ -480,6 +483,13 @@ class InferenceExecutor:
             self._spec = (list(sequences), bs, [s.num_tokens + 1 for s in sequences], self._stash_tokens(b), graph)
         self._tok_events[slot_now].synchronize()
         return (gv["logits_local"] if greedy else gv["logits"])[:b], self._tok_host[slot_now][:b].tolist()
+
+    def _drop_speculation(self) -> None:
+        """Forget the speculative step in flight (its tokens are never read) and give its Philox step count
+        back, so that the random stream of the real steps does not depend on what was speculated."""
+        if self._spec is not None:
+            self._spec = None
+            self.sampler.calls -= 1
 
     def _stash_tokens(self, b: int) -> int:
         """Async D2H of the step that was just enqueued into a pinned ring slot + an event to wait on."""

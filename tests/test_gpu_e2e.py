@@ -367,8 +367,8 @@ def test_kv_cache_auto_sizing_and_graph_buckets(golden_dir, tmp_path):
 
 
 def test_randomized_serving_speculation_changes_nothing(golden_dir, tmp_path, monkeypatch):
-    """Continuous batching under pressure: 40 requests with random lengths / budgets / shared prefixes
-    arriving while others decode, a KV pool small enough to force preemption and recomputation, prefix-cache
+    """Continuous batching under pressure: 40 requests (greedy, nucleus and top-k sampled rows mixed in one
+    batch) with random lengths / budgets / shared prefixes arriving while others decode, a KV pool small enough to force preemption and recomputation, prefix-cache
     hits, block edges, EOS stops.  The captured-graph path is run twice, with and without the speculative
     replay of the next step: every request must get exactly the same tokens (same buckets, same kernels; the
     speculation only changes WHEN a step is enqueued).  Against eager decoding the batch is padded to a
@@ -389,7 +389,9 @@ def test_randomized_serving_speculation_changes_nothing(golden_dir, tmp_path, mo
     for i in range(40):
         body = [rng.randrange(3, 300) for _ in range(rng.choice((1, 5, 20, 62, 63, 64, 65, 100)))]
         prompt = (shared + body) if i % 3 == 0 else body
-        reqs.append((prompt, SamplingParams(temperature=0.0, max_tokens=rng.choice((1, 2, 7, 20, 33, 70)),
+        temp, top_p, top_k = ((0.0, 1.0, -1), (0.8, 0.9, -1), (1.0, 1.0, 20))[i % 3 if i % 2 else 0]
+        reqs.append((prompt, SamplingParams(temperature=temp, top_p=top_p, top_k=top_k,
+                                            max_tokens=rng.choice((1, 2, 7, 20, 33, 70)),
                                             ignore_eos=(i % 4 != 0)), rng.randrange(0, 60)))
 
     def serve(eager, speculate):
@@ -421,6 +423,7 @@ def test_randomized_serving_speculation_changes_nothing(golden_dir, tmp_path, mo
     assert st0[0] == 0 and st1[0] > 20, (st0, st1)                      # really speculated (arrivals discard some)
     assert st0[2] == st1[2] > 0, (st0, st1)                             # the pool did run dry: preemptions
     assert spec == plain
+    # (the Philox stream of a step is keyed by the step count, which the device-side advance reproduces: sampled
+    # rows are identical too.)  Eager: same scheduler, same seeds -- only the split-KV padding differs
     eager, _ = serve(eager=True, speculate=False)
-    assert [len(t) for t in eager] == [len(t) for t in plain] or sum(a == b for a, b in zip(eager, plain)) >= 36
-    assert sum(a == b for a, b in zip(eager, plain)) >= 36
+    assert sum(a == b for a, b in zip(eager, plain)) >= 30
