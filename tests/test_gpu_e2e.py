@@ -200,6 +200,34 @@ def test_engine_generate_greedy_eager_equals_graphs(golden_dir, tmp_path):
     assert results[0] == results[1]
 
 
+def test_full_batch_off_the_bucket_grid_runs_on_a_graph(golden_dir, tmp_path):
+    """max_num_seqs = 24 is not a multiple of 16: the bucket list ends with 24 itself, so a full batch of 24
+    decodes on a captured graph (speculatively, too) and produces the eager tokens for nearly every request."""
+    from minivllm_amd import LLM, Config, SamplingParams
+
+    z = _load(golden_dir, "qwen3")
+    d = tmp_path / "m"
+    d.mkdir()
+    (d / "config.json").write_text(bytes(z["config_json"]).decode())
+    weights = {k[2:]: torch.from_numpy(z[k].view(np.int16).copy()).view(torch.bfloat16).float()
+               for k in z.files if k.startswith("w:")}
+    prompts = [[3 + (5 * i + j) % 290 for j in range(4 + i)] for i in range(24)]
+    results, stats = [], []
+    for eager in (True, False):
+        cfg = Config(str(d), max_model_len=512, max_num_batched_tokens=1024, max_num_seqs=24, enforce_eager=eager,
+                     dtype="bfloat16", num_kvcache_blocks=40, load_format="dummy", seed=0)
+        engine = LLM(cfg)
+        engine.model_runner.model_manager.model.load_weights(weights)
+        ex = engine.model_runner.inference_executor
+        outs = engine.generate(prompts, SamplingParams(temperature=0.0, max_tokens=20, ignore_eos=True), use_tqdm=False)
+        results.append([o["token_ids"] for o in outs])
+        stats.append((sorted(ex.graphs), ex.spec_hits))
+        engine.exit()
+    assert stats[1][0] == [1, 2, 4, 8, 12, 16, 24] and stats[1][1] > 5 and stats[0] == ([], 0)
+    # bucket 24 for 24 rows: no padding, the same split-KV plan as eager -> bit-identical step inputs
+    assert results[0] == results[1]
+
+
 def test_llm_from_checkpoint_dir_with_tokenizer(golden_dir, tmp_path):
     """The full user path: a model directory with config.json + model.safetensors (HF names) + a
     tokenizer; ``LLM(Config(dir))`` loads it (load_format="auto"), string prompts are tokenised,
