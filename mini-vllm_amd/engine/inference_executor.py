@@ -504,7 +504,8 @@ class InferenceExecutor:
         for s in sequences:
             # after this step the sequence has num_tokens + 1 tokens; the step after that needs a new block
             # iff num_tokens % bs == 0, and there is no such step if this token exhausts max_tokens
-            if s.num_tokens % bs == 0 or s.num_completion_tokens + 1 >= s.max_tokens:
+            if (s.num_tokens % bs == 0 or s.num_completion_tokens + 1 >= s.max_tokens
+                    or s.num_tokens + 1 >= self.config.max_model_len):
                 return False
         return True
 

@@ -21,6 +21,7 @@ class Scheduler:
         self.max_num_seqs = config.max_num_seqs
         self.max_num_batched_tokens = config.max_num_batched_tokens
         self.eos = config.eos
+        self.max_model_len = getattr(config, "max_model_len", None) or (1 << 62)
         self.block_manager = BlockManager(config.num_kvcache_blocks, config.kvcache_block_size)
         self.waiting: deque[Sequence] = deque()
         self.running: deque[Sequence] = deque()
@@ -128,7 +129,9 @@ class Scheduler:
         for seq, token in zip(sequences, token_ids, strict=True):
             seq.append_token(token)
             hit_eos = token == self.eos and not seq.ignore_eos
-            if hit_eos or seq.num_completion_tokens >= seq.max_tokens:
+            # beyond the reference: a sequence that fills max_model_len stops there (the reference walks off the
+            # end of its block-table staging buffer with an index error)
+            if hit_eos or seq.num_completion_tokens >= seq.max_tokens or len(seq) >= self.max_model_len:
                 seq.status = SequenceStatus.FINISHED
                 self.block_manager.deallocate(seq)
                 self.running.remove(seq)

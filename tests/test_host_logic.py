@@ -169,6 +169,23 @@ def test_block_pressure_preempts_instead_of_raising():
     assert a.num_completion_tokens == 40 and b.num_completion_tokens == 40
 
 
+def test_generation_stops_at_max_model_len():
+    """Beyond the reference (it runs off the end of its block-table staging buffer): a sequence that has filled
+    max_model_len finishes there, whatever max_tokens says; shorter ones are unaffected."""
+    cfg = SimpleNamespace(max_num_seqs=4, max_num_batched_tokens=512, eos=-1, num_kvcache_blocks=8,
+                          kvcache_block_size=64, max_model_len=128)
+    sched = Scheduler(cfg)
+    long_, short = (Sequence([5] * 120, SamplingParams(max_tokens=40, ignore_eos=True)),
+                    Sequence([7] * 10, SamplingParams(max_tokens=40, ignore_eos=True)))
+    sched.add(long_)
+    sched.add(short)
+    while not sched.is_finished():
+        batch, _ = sched.schedule()
+        sched.postprocess(batch, [1] * len(batch))
+    assert (len(long_), long_.num_completion_tokens) == (128, 8) and short.num_completion_tokens == 40
+    assert long_.status == SequenceStatus.FINISHED and len(long_.block_table) == 0
+
+
 def test_sequence_block_math_and_pickle():
     s = Sequence(list(range(130)), SamplingParams(temperature=0.5, top_k=7, max_tokens=9), block_size=64)
     assert (s.num_blocks, s.last_block_num_tokens, s.num_cached_blocks) == (3, 2, 0)
