@@ -110,6 +110,10 @@ class LLMEngine:
             if self.tokenizer is None:
                 raise RuntimeError("no tokenizer loaded: pass prompts as lists of token ids")
             prompt = self.tokenizer.encode(prompt)
+        limit = min(self.config.max_num_batched_tokens, self.config.max_model_len)
+        if len(prompt) > limit:
+            # beyond the reference, whose scheduler only notices when nothing can be scheduled any more
+            raise ValueError(f"prompt of {len(prompt)} tokens exceeds min(max_num_batched_tokens, max_model_len) = {limit}")
         seq = Sequence(prompt, sampling_params, block_size=self.config.kvcache_block_size)
         self.scheduler.add(seq)
         return seq.seq_id
