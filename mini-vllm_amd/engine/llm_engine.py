@@ -111,9 +111,11 @@ class LLMEngine:
                 raise RuntimeError("no tokenizer loaded: pass prompts as lists of token ids")
             prompt = self.tokenizer.encode(prompt)
         limit = min(self.config.max_num_batched_tokens, self.config.max_model_len)
+        if self.config.num_kvcache_blocks > 0:   # (-1 before the KV cache is sized)
+            limit = min(limit, self.config.num_kvcache_blocks * self.config.kvcache_block_size)
         if len(prompt) > limit:
             # beyond the reference, whose scheduler only notices when nothing can be scheduled any more
-            raise ValueError(f"prompt of {len(prompt)} tokens exceeds min(max_num_batched_tokens, max_model_len) = {limit}")
+            raise ValueError(f"prompt of {len(prompt)} tokens exceeds what one prefill can take (max_num_batched_tokens, max_model_len, KV pool): {limit}")
         seq = Sequence(prompt, sampling_params, block_size=self.config.kvcache_block_size)
         self.scheduler.add(seq)
         return seq.seq_id
