@@ -21,8 +21,11 @@ class Scheduler:
         self.max_num_seqs = config.max_num_seqs
         self.max_num_batched_tokens = config.max_num_batched_tokens
         self.eos = config.eos
-        self.max_model_len = getattr(config, "max_model_len", None) or (1 << 62)
         self.block_manager = BlockManager(config.num_kvcache_blocks, config.kvcache_block_size)
+        # a sequence stops when it fills max_model_len -- or the whole KV pool (alone in it, it could only
+        # preempt and re-prefill itself for ever)
+        self.max_model_len = min(getattr(config, "max_model_len", None) or (1 << 62),
+                                 config.num_kvcache_blocks * config.kvcache_block_size)
         self.waiting: deque[Sequence] = deque()
         self.running: deque[Sequence] = deque()
         self.num_preemptions = 0

@@ -186,6 +186,21 @@ def test_generation_stops_at_max_model_len():
     assert long_.status == SequenceStatus.FINISHED and len(long_.block_table) == 0
 
 
+def test_sequence_alone_in_a_full_pool_finishes_instead_of_preempting_itself_forever():
+    cfg = SimpleNamespace(max_num_seqs=4, max_num_batched_tokens=512, eos=-1, num_kvcache_blocks=2,
+                          kvcache_block_size=64, max_model_len=4096)
+    sched = Scheduler(cfg)
+    seq = Sequence([5] * 100, SamplingParams(max_tokens=100, ignore_eos=True))
+    sched.add(seq)
+    steps = 0
+    while not sched.is_finished():
+        batch, _ = sched.schedule()
+        sched.postprocess(batch, [1] * len(batch))
+        steps += 1
+        assert steps < 100
+    assert len(seq) == 128 and sched.num_preemptions == 0
+
+
 def test_sequence_block_math_and_pickle():
     s = Sequence(list(range(130)), SamplingParams(temperature=0.5, top_k=7, max_tokens=9), block_size=64)
     assert (s.num_blocks, s.last_block_num_tokens, s.num_cached_blocks) == (3, 2, 0)
