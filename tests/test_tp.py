@@ -299,8 +299,8 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
     kw = dict(max_model_len=512, max_num_batched_tokens=1024, max_num_seqs=8, num_kvcache_blocks=24,
               enforce_eager=True)
 
-    def run(tp, dtype, eager=True):
-        llm = LLM(Config(str(d), dtype=dtype, tensor_parallel_size=tp, **{**kw, "enforce_eager": eager}))
+    def run(tp, dtype, eager=True, sp=sp):
+        llm = LLM(Config(str(d), dtype=dtype, tensor_parallel_size=tp, seed=3, **{**kw, "enforce_eager": eager}))
         try:
             ex = llm.model_runner.inference_executor
             from minivllm_amd import parallel_state
@@ -313,6 +313,10 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
     monkeypatch.setenv("MINIVLLM_TP_BACKEND", "gloo")
     # fp32: TP only reorders fp32 sums (1e-6 relative) -> identical greedy tokens
     assert run(2, "float32")[0] == run(1, "float32")[0]
+    # sampled rows: every rank draws from the same gathered logits with the same Philox stream, and that stream
+    # does not depend on the TP degree (fp32: the probabilities agree to ~1e-6)
+    sampled = SamplingParams(temperature=0.8, top_p=0.95, top_k=50, max_tokens=12, ignore_eos=True)
+    assert run(2, "float32", sp=sampled)[0] == run(1, "float32", sp=sampled)[0]
     # bf16 (all-reduces on the peer-to-peer kernel): same lengths, and the first tokens agree (later ones may
     # legitimately diverge after a near-tie, as between any two bf16 summation orders)
     (a, *_), (b, *_) = run(2, "bfloat16"), run(1, "bfloat16")
