@@ -191,6 +191,39 @@ int mv_gate_up_silu_small_m(const void *x, int64_t x_stride, const void *w_gate_
                             void *out, int64_t out_stride, int m, int n_inter,
                             int k, int dtype, void *stream);
 
+/* K11 — decode-batch linear layer for 17..512 rows (the headline batch, max_num_seqs = 256): same contract as
+ * mv_linear_small_m (fp32 accumulation, bias in fp32, one rounding) with K % 64 == 0, N % 4 == 0.  Replaces the
+ * F.linear calls of minivllm/models/layers/linear.py:130,163,316 where the library GEMM is bound by how fast a CU
+ * takes bytes in, not by HBM or the matrix cores (mini-vllm_amd/csrc/linear_mid_m.hip).
+ * The weight comes RE-PACKED (once, at load time) by mv_pack_weight: [ceil(N/16)][K/32][64][8] elements, the
+ * A-operand fragment order of v_mfma_f32_16x16x32 (lane l = row l & 15, k group l >> 4), rows beyond N zero;
+ * mv_packed_weight_elems(n, k) elements.  A workgroup's weight share is then a set of linear HBM streams
+ * (6.8 TB/s measured against 4.4 TB/s for 128-byte pieces of row-major rows).
+ * `cfg` selects the workgroup tile (0 = chosen from the shape; 1.. = the table in linear_mid_m.hip, for
+ * tools/bench_mid.py; +100 = the DMA ring alone, nothing computed or written; +200 = K loop rotated per workgroup). */
+size_t mv_packed_weight_elems(int n, int k);
+int mv_pack_weight(const void *w, void *w_packed, int n, int k, int dtype, void *stream);
+int mv_linear_mid_m(const void *x, int64_t x_stride, const void *w_packed, const void *bias,
+                    void *out, int64_t out_stride, int m, int n, int k, int dtype,
+                    int cfg, void *stream);
+/* K11 + K9 — merged gate_up projection ([gate rows ; up rows], packed as ONE [2*n_inter, K] matrix,
+ * n_inter % 16 == 0) with SiluAndMul in the epilogue (see mv_gate_up_silu_small_m for the rounding points). */
+int mv_gate_up_silu_mid_m(const void *x, int64_t x_stride, const void *w_gate_up_packed,
+                          void *out, int64_t out_stride, int m, int n_inter, int k,
+                          int dtype, int cfg, void *stream);
+/* K11, K split over `splits` workgroup groups: out_partial [splits][m][n] fp32, unrounded, no bias; the
+ * consumer kernel behind it sums the slices in split order (deterministic). */
+int mv_linear_mid_m_partial(const void *x, int64_t x_stride, const void *w_packed,
+                            float *out_partial, int m, int n, int k, int splits,
+                            int dtype, int cfg, void *stream);
+
+/* K6 behind a K-split projection: mv_add_rmsnorm whose x is the sum of `splits` fp32 partial results
+ * [splits][rows][cols] of mv_linear_mid_m_partial, summed in split order and rounded to dtype first (the rounding
+ * point of the GEMM output that RMSNorm.add_rms_forward reads, minivllm/models/layers/layernorm.py:95-105). */
+int mv_add_rmsnorm_partial(const float *partial, int splits, void *residual, int64_t res_stride,
+                           const void *w, void *out, int64_t out_stride, int rows, int cols,
+                           float eps, int dtype, void *stream);
+
 /* C1 — small-message all-reduce over xGMI peer-to-peer loads, for the [tokens, hidden] sums of a
  * tensor-parallel decode step.  Replaces dist.all_reduce in RowParallelLinear.forward and
  * VocabParallelEmbedding.forward (minivllm/models/layers/linear.py:316-318, layers/embed_head.py:170-173)

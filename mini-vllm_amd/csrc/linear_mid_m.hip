@@ -1,0 +1,450 @@
+// K11 — y[M,N] = x[M,K] · W[N,K]ᵀ (+ bias) for decode batches of 17..512 rows: the projections of a decode
+// step (minivllm/models/layers/linear.py:130,163,316 -> F.linear) at the batch sizes the headline is quoted on
+// (max_num_seqs = 256).
+//
+// Why not the library GEMM here.  At M = 256 a layer's projections are 8-270 MB weight streams of 4-70 GFLOP.
+// Measured on MI355X (tools/dbg/ingest_probe*.hip, profiles/r02_ingest_probe.md): what bounds them is how fast
+// a CU can take bytes in — ~100-135 GB/s per CU for the L2-resident x that EVERY workgroup re-reads, and an HBM
+// stream that runs at 4.4 TB/s when it is fetched as 128-byte pieces of 4-KB-strided weight rows (what a
+// row-major [N][K] tile is) against 6.8 TB/s when the same bytes are contiguous.  hipBLASLt runs these shapes at
+// 1.2-2.1 TB/s.  So:
+//   * the weights are RE-PACKED once at load time (mv_pack_weight) into MFMA-fragment order:
+//     [N/16][K/32][64 lanes][8 elements], lane l = (row l&15, k-group l>>4) — the A operand of
+//     v_mfma_f32_16x16x32 for 16 weight rows x 32 k.  A workgroup's share of W is then BN/16 perfectly linear
+//     streams, each DMA piece is one 1-KiB fragment, and the fragment lands in LDS in lane order: the
+//     ds_read_b128 that fetches it is conflict-free with no swizzle;
+//   * x stays row-major (it is produced by the kernel in front): whole 128-byte rows by LDS-DMA, 8 rows per
+//     wave instruction, XOR swizzle applied on the SOURCE address, fragments by conflict-free ds_read_b128;
+//   * dedicated LOADER waves issue every DMA (x loaders and W loaders, each with its own ring depth: the
+//     in-order vmcnt of a wave would otherwise tie the HBM stream's prefetch depth to the L2 stream's), so the
+//     COMPUTE waves never stall in a saturated memory pipeline; one raw s_barrier per 64-deep k-block hands a
+//     landed block over and frees the slot read one block earlier; counted s_waitcnt vmcnt, never 0 in the loop;
+//   * compute waves read the fragments of the next k-step while the MFMAs of the current one run (two
+//     register sets, the barrier sits between the two k-steps of a block);
+//   * (tried: every workgroup starting its K loop at a different k-block, so that 256 workgroups do not ask
+//     the same L2 lines of x at the same moment — no gain, -12 % on the widest layer; `krot` stays as a
+//     bench switch, off: the K order is then the natural one and the results equal the library GEMM's bit for bit);
+//   * tile BM x BN per shape so that (BM + BN) * K * 2 bytes per workgroup is smallest while the grid covers
+//     the chip once; blocks b and b+8 (same XCD under round-robin placement: speed only) take the row halves
+//     of the same weight tile, so the second read of a weight fragment is an L2 hit.
+// Epilogues: bias in fp32 + one rounding (the GEMM's rounding point); GATED = SiluAndMul with the rounding
+// points of the unfused pair (GEMM -> dtype, silu -> dtype, product -> dtype; activation.py:70-96);
+// PARTIAL = fp32 partial sums of a K split, summed by the consumer kernel behind it.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+template <typename Tag>
+__device__ __forceinline__ f32x4 mfma16(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
+  if constexpr (__is_same(Tag, bf16_tag))
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+enum { EPI_PLAIN = 0, EPI_GATED = 1, EPI_PARTIAL = 2, EPI_INGEST = 3 };
+
+struct MidParams {
+  const void *x, *wp, *bias;
+  void *out;          // [M][N] dtype (PARTIAL: fp32 [splits][M][N])
+  int64_t x_stride, out_stride;
+  int M, N, K;        // N = output columns (GATED: the packed W has 2N rows, the up rows start at row N)
+  int n_tiles, m_tiles;
+  int kb_per_split;   // 64-element k-blocks per K split (blockIdx.y)
+  int krot;           // rotate the K loop start per workgroup
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `ahead` later blocks (P pieces each) of this wave are still in flight; ahead <= A
+template <int P, int A>
+__device__ __forceinline__ void wait_ahead(int ahead) {
+  if (ahead >= A) wait_vmcnt<A * P>();
+  else if constexpr (A > 0) wait_ahead<P, A - 1>(ahead);
+}
+
+// PIPE: two fragment register sets (reads of the next k-step under the MFMAs of this one); 0 for the widest tiles
+template <typename Tag, int BM, int BN, int WM, int WN, int NLX, int NLW, int SX, int SW, int PIPE, int EPI>
+__global__ void __launch_bounds__((WM * WN + NLX + NLW) * 64) linear_mid_m_kernel(MidParams p) {
+  typedef uint16_t T;
+  constexpr int NWC = WM * WN;                          // compute waves; then NLX x-loaders, NLW W-loaders
+  constexpr int XS = BM * 128, WS = BN * 128;           // bytes of one k-block (64 elements) of x / of W
+  constexpr int PX = BM / 8 / NLX, PW = BN / 8 / NLW;   // 1-KiB DMA pieces per loader wave and k-block
+  static_assert((BM / 8) % NLX == 0 && (BN / 8) % NLW == 0, "pieces must divide over the loader waves");
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;   // 16x16 tiles per compute wave
+  static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "wave tile");
+  static_assert(EPI != EPI_GATED || (TN % 2 == 0 && BN % 32 == 0), "gated: gate and up tiles pair up inside a wave");
+  static_assert((SX - 2) * PX <= 63 && (SW - 2) * PW <= 63, "vmcnt is a 6-bit counter");
+  static_assert(SX >= 2 && SW >= 2, "ring depth");
+  extern __shared__ __attribute__((aligned(1024))) char lds[];   // the ONE shared object: [SX][XS] then [SW][WS]
+  char *const xl = lds, *const wl = lds + SX * XS;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  // block -> (weight tile, row tile): ids b and b+8 share a weight tile
+  const int per_q = 8 * p.m_tiles;
+  const int q = blockIdx.x / per_q, r = blockIdx.x % per_q;
+  const int n_tile = q * 8 + (r & 7), m_tile = r >> 3;
+  if (n_tile >= p.n_tiles) return;
+  constexpr int BNO = EPI == EPI_GATED ? BN / 2 : BN;   // output columns per tile
+  const int m0 = m_tile * BM, n0 = n_tile * BNO;
+  const int kb_total = p.K >> 6;
+  const int kb_lo = blockIdx.y * p.kb_per_split;
+  const int nk = min(p.kb_per_split, kb_total - kb_lo);
+  const int rot = p.krot && nk > 0 ? (n_tile * 5 + m_tile * 3) % nk : 0;
+  auto kb_of = [&](int i) {   // i-th k-block this workgroup works on
+    int kb = i + rot;
+    if (kb >= nk) kb -= nk;
+    return kb_lo + kb;
+  };
+
+  if (wave >= NWC) {
+    // ================================ loader waves ================================
+    const int lw = wave - NWC;
+    if (lw < NLX) {
+      // x: piece = 8 rows x 128 B; lane -> (row, stored chunk) fetches the logical chunk stored ^ (row & 7)
+      const T *src[PX];
+#pragma unroll
+      for (int j = 0; j < PX; ++j) {
+        const int row = (lw + j * NLX) * 8 + (lane >> 3);
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;                        // ragged last row tile: re-read the last row
+        src[j] = (const T *)p.x + (int64_t)m * p.x_stride + (((lane & 7) ^ (row & 7)) << 3);
+      }
+      auto issue = [&](int i, int slot) {
+        char *dst = xl + slot * XS + lw * 1024;
+        const int koff = kb_of(i) * 64;
+#pragma unroll
+        for (int j = 0; j < PX; ++j)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[j] + koff),
+                                           (__attribute__((address_space(3))) void *)(dst + j * NLX * 1024), 16, 0, 0);
+      };
+#pragma unroll
+      for (int s = 0; s < SX - 1; ++s)
+        if (s < nk) issue(s, s);
+      for (int i = 0; i < nk; ++i) {
+        wait_ahead<PX, SX - 2>(min(nk - 1 - i, SX - 2));
+        __builtin_amdgcn_s_barrier();   // block i handed over; the slot of block i-1 is free
+        if (i + SX - 1 < nk) issue(i + SX - 1, (i + SX - 1) % SX);
+      }
+    } else {
+      // W: piece = one packed fragment (16 rows x 32 k = 1 KiB, linear); LDS: [BN/16 tiles][2 k-steps][1 KiB]
+      const int lw2 = lw - NLX;
+      const int kfrags = p.K >> 5;
+      const int n16_last = ((EPI == EPI_GATED ? 2 * p.N : p.N) + 15) / 16 - 1;
+      const T *src[PW];
+#pragma unroll
+      for (int j = 0; j < PW; ++j) {
+        const int piece = lw2 + j * NLW, t = piece >> 1, ks = piece & 1;
+        int n16;
+        if constexpr (EPI == EPI_GATED) {
+          // compute wave column w_ owns LDS tiles [w_*TN, (w_+1)*TN): TN/2 gate tiles then TN/2 up tiles
+          const int w_ = t / TN, tt = t % TN;
+          n16 = n0 / 16 + w_ * (TN / 2) + tt % (TN / 2);
+          n16 = min(n16, p.N / 16 - 1);
+          if (tt >= TN / 2) n16 += p.N / 16;
+        } else {
+          n16 = min(n0 / 16 + t, n16_last);
+        }
+        src[j] = (const T *)p.wp + ((int64_t)n16 * kfrags + ks) * 512 + lane * 8;
+      }
+      auto issue = [&](int i, int slot) {
+        char *dst = wl + slot * WS + lw2 * 1024;
+        const int koff = kb_of(i) * 1024;   // 2 fragments of 512 elements per k-block
+#pragma unroll
+        for (int j = 0; j < PW; ++j)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[j] + koff),
+                                           (__attribute__((address_space(3))) void *)(dst + j * NLW * 1024), 16, 0, 2);
+      };
+#pragma unroll
+      for (int s = 0; s < SW - 1; ++s)
+        if (s < nk) issue(s, s);
+      for (int i = 0; i < nk; ++i) {
+        wait_ahead<PW, SW - 2>(min(nk - 1 - i, SW - 2));
+        __builtin_amdgcn_s_barrier();
+        if (i + SW - 1 < nk) issue(i + SW - 1, (i + SW - 1) % SW);
+      }
+    }
+    return;
+  }
+
+  // ================================ compute waves ================================
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if constexpr (EPI == EPI_INGEST) {
+    for (int i = 0; i < nk; ++i) __builtin_amdgcn_s_barrier();
+    if (p.out && nk < 0) ((float *)p.out)[threadIdx.x] = acc[0][0][0];   // never true
+    return;
+  } else {
+    // fragment read offsets inside a block (x: row & 7 == r16 & 7, tile bases are multiples of 16)
+    const int sw = r16 & 7;
+    const int xoff = (wm * TM * 16 + r16) * 128;
+    const int xc[2] = {((g) ^ sw) << 4, ((4 + g) ^ sw) << 4};
+    const int woff = wn * TN * 2048 + lane * 16;
+    auto read = [&](int i, int s, u32x4(&xf)[TM], u32x4(&wf)[TN]) {
+      const char *xs = xl + (i % SX) * XS + xoff + xc[s];
+      const char *ws = wl + (i % SW) * WS + woff + s * 1024;
+#pragma unroll
+      for (int b = 0; b < TM; ++b) xf[b] = *(const u32x4 *)(xs + b * 2048);
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4 *)(ws + a * 2048);
+    };
+    auto mma = [&](const u32x4(&xf)[TM], const u32x4(&wf)[TN]) {
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = mfma16<Tag>(wf[a], xf[b], acc[a][b]);
+    };
+    if constexpr (!PIPE) {
+      u32x4 xa[TM], wa[TN];
+      for (int i = 0; i < nk; ++i) {
+        __builtin_amdgcn_s_barrier();   // block i has landed; every read of block i-1 has been consumed
+        read(i, 0, xa, wa);
+        mma(xa, wa);
+        read(i, 1, xa, wa);
+        mma(xa, wa);
+      }
+    } else {
+    u32x4 xa[TM], wa[TN], xb[TM], wb[TN];
+    if (nk > 0) {
+      __builtin_amdgcn_s_barrier();   // block 0 has landed
+      read(0, 0, xa, wa);
+    }
+    for (int i = 0; i < nk; ++i) {
+      read(i, 1, xb, wb);
+      mma(xa, wa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < nk) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of block i are done: its slot may be refilled
+        __builtin_amdgcn_s_barrier();                          // block i+1 has landed
+        read(i + 1, 0, xa, wa);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(xb, wb);
+    }
+    }
+  }
+
+  // ---- epilogue: lane holds rows n = g*4 + {0..3} of W (consecutive output columns) for token m = r16
+  if constexpr (EPI == EPI_GATED) {
+#pragma unroll
+    for (int a = 0; a < TN / 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int m = m0 + (wm * TM + b) * 16 + r16;
+        const int n = n0 + (wn * (TN / 2) + a) * 16 + g * 4;
+        if (m < p.M && n < p.N) {
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float gt = elem<Tag>::ld(elem<Tag>::st(acc[a][b][e]));            // the GEMM output as stored
+            const float ut = elem<Tag>::ld(elem<Tag>::st(acc[a + TN / 2][b][e]));
+            float sl = gt / (1.0f + expf(-gt));                                       // rmsnorm.hip: silu_and_mul_kernel
+            sl = elem<Tag>::ld(elem<Tag>::st(sl));
+            o[e] = __fmul_rn(sl, ut);
+          }
+          u32x2 pk;
+          pk[0] = (uint32_t)elem<Tag>::st(o[0]) | ((uint32_t)elem<Tag>::st(o[1]) << 16);
+          pk[1] = (uint32_t)elem<Tag>::st(o[2]) | ((uint32_t)elem<Tag>::st(o[3]) << 16);
+          *(u32x2 *)((T *)p.out + (int64_t)m * p.out_stride + n) = pk;
+        }
+      }
+  } else if constexpr (EPI == EPI_PLAIN || EPI == EPI_PARTIAL) {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int m = m0 + (wm * TM + b) * 16 + r16;
+        const int n = n0 + (wn * TN + a) * 16 + g * 4;
+        if (m < p.M && n < p.N) {
+          if constexpr (EPI == EPI_PARTIAL) {
+            float *dst = (float *)p.out + ((int64_t)blockIdx.y * p.M + m) * p.out_stride + n;
+            *(f32x4 *)dst = acc[a][b];
+          } else {
+            float o[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+            if (p.bias) {
+              const T *bp = (const T *)p.bias + n;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] += elem<Tag>::ld(bp[e]);
+            }
+            u32x2 pk;
+            pk[0] = (uint32_t)elem<Tag>::st(o[0]) | ((uint32_t)elem<Tag>::st(o[1]) << 16);
+            pk[1] = (uint32_t)elem<Tag>::st(o[2]) | ((uint32_t)elem<Tag>::st(o[3]) << 16);
+            *(u32x2 *)((T *)p.out + (int64_t)m * p.out_stride + n) = pk;
+          }
+        }
+      }
+  }
+}
+
+// re-pack W [N][K] row-major -> [ceil(N/16)][K/32][64 lanes][8]; rows beyond N are zeros
+template <typename T16>
+__global__ void pack_weight_kernel(const uint16_t *w, uint16_t *wp, int N, int K, int64_t chunks) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= chunks) return;
+  const int kfrags = K >> 5;
+  const int lane = (int)(c & 63);
+  const int64_t f = c >> 6;
+  const int kb = (int)(f % kfrags);
+  const int n = (int)(f / kfrags) * 16 + (lane & 15);
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (n < N) v = *(const u32x4 *)(w + (int64_t)n * K + kb * 32 + (lane >> 4) * 8);
+  *(u32x4 *)(wp + c * 8) = v;
+}
+
+// ---- launch shapes ------------------------------------------------------------------------------------
+struct Cfg { int bm, bn, wm, wn, nlx, nlw, sx, sw; bool gated_ok; };
+// id -> tile; ids are part of the C-ABI (mv_linear_mid_m's `cfg`), 0 = chosen here
+constexpr Cfg kCfgs[] = {
+    {0, 0, 0, 0, 0, 0, 0, 0, false},
+    {128, 96, 4, 1, 2, 2, 4, 7, true},     // 1: 148 KB
+    {256, 48, 4, 1, 4, 2, 3, 8, false},    // 2: 144 KB
+    {128, 32, 4, 1, 2, 1, 5, 12, true},    // 3: 128 KB
+    {64, 32, 2, 2, 1, 1, 8, 12, false},    // 4: 112 KB
+    {256, 64, 4, 1, 4, 2, 3, 7, true},     // 5: 152 KB
+    {128, 128, 4, 2, 2, 2, 4, 5, true},    // 6: 144 KB
+    {256, 160, 8, 1, 2, 2, 3, 3, true},    // 7: 156 KB, one fragment set (Qwen2-7B gate_up: 237 workgroups)
+    {256, 128, 4, 2, 2, 2, 3, 4, true},    // 8: 160 KB
+    {128, 48, 4, 1, 2, 1, 5, 12, false},   // 9: 152 KB
+    {64, 64, 2, 2, 1, 1, 8, 9, true},      // 10: 136 KB
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+template <typename Tag, int BM, int BN, int WM, int WN, int NLX, int NLW, int SX, int SW, int PIPE, int EPI>
+int launch_one(const MidParams &p, int splits, hipStream_t st) {
+  constexpr size_t lds = (size_t)SX * BM * 128 + (size_t)SW * BN * 128;
+  static_assert(lds <= 160 * 1024, "LDS ring");
+  auto kern = linear_mid_m_kernel<Tag, BM, BN, WM, WN, NLX, NLW, SX, SW, PIPE, EPI>;
+  static bool attr_set = false;   // idempotent: the same value every time (not state the results depend on)
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(((p.n_tiles + 7) / 8) * 8 * p.m_tiles, splits), block((WM * WN + NLX + NLW) * 64);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, p);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+template <typename Tag, int EPI>
+int launch_cfg(MidParams p, int cfg, int splits, hipStream_t st) {
+  const Cfg c = kCfgs[cfg];
+  constexpr bool G = EPI == EPI_GATED;
+  p.m_tiles = (p.M + c.bm - 1) / c.bm;
+  const int bno = G ? c.bn / 2 : c.bn;
+  p.n_tiles = (p.N + bno - 1) / bno;
+  const int kb = p.K / 64;
+  p.kb_per_split = (kb + splits - 1) / splits;
+  switch (cfg) {
+    case 1: return launch_one<Tag, 128, 96, 4, 1, 2, 2, 4, 7, 1, EPI>(p, splits, st);
+    case 2: if constexpr (!G) return launch_one<Tag, 256, 48, 4, 1, 4, 2, 3, 8, 1, EPI>(p, splits, st); else break;
+    case 3: return launch_one<Tag, 128, 32, 4, 1, 2, 1, 5, 12, 1, EPI>(p, splits, st);
+    case 4: if constexpr (!G) return launch_one<Tag, 64, 32, 2, 2, 1, 1, 8, 12, 1, EPI>(p, splits, st); else break;
+    case 5: return launch_one<Tag, 256, 64, 4, 1, 4, 2, 3, 7, 1, EPI>(p, splits, st);
+    case 6: return launch_one<Tag, 128, 128, 4, 2, 2, 2, 4, 5, 1, EPI>(p, splits, st);
+    case 7: return launch_one<Tag, 256, 160, 8, 1, 2, 2, 3, 3, 0, EPI>(p, splits, st);
+    case 8: return launch_one<Tag, 256, 128, 4, 2, 2, 2, 3, 4, 1, EPI>(p, splits, st);
+    case 9: if constexpr (!G) return launch_one<Tag, 128, 48, 4, 1, 2, 1, 5, 12, 1, EPI>(p, splits, st); else break;
+    case 10: return launch_one<Tag, 64, 64, 2, 2, 1, 1, 8, 9, 1, EPI>(p, splits, st);
+    default: break;
+  }
+  return MV_E_RANGE;
+}
+
+int auto_cfg(int m, int n, int k, bool gated) {
+  // smallest ingest per workgroup among the tiles whose grid covers the chip once (<= 256 workgroups)
+  int best = 1;
+  double best_cost = 1e30;
+  for (int id = 1; id < kNumCfgs; ++id) {
+    const Cfg c = kCfgs[id];
+    if (gated && !c.gated_ok) continue;
+    const int bno = gated ? c.bn / 2 : c.bn;
+    const int wgs = ((m + c.bm - 1) / c.bm) * ((n + bno - 1) / bno);
+    const int rounds = (wgs + 255) / 256;
+    const double cost = (double)rounds * (c.bm + c.bn) + (wgs < 128 ? 1e6 : 0);
+    if (cost < best_cost) best_cost = cost, best = id;
+  }
+  return best;
+}
+
+int check(const void *x, int64_t x_stride, const void *w, void *out, int64_t out_stride, int m, int n, int k,
+          int dtype) {
+  if (!x || !w || !out) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (m < 0 || n < 0 || k < 64 || (k & 63) || (n & 3)) return MV_E_SHAPE;
+  if (!mv_aligned16(x) || !mv_aligned16(w) || (((uintptr_t)out) & 7u) || (x_stride & 7) || (out_stride & 3))
+    return MV_E_ALIGN;
+  return MV_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mv_packed_weight_elems(int n, int k) { return (size_t)((n + 15) / 16) * 16 * (size_t)k; }
+
+extern "C" int mv_pack_weight(const void *w, void *w_packed, int n, int k, int dtype, void *stream) {
+  if (n == 0 || k == 0) return MV_OK;
+  if (!w || !w_packed) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (n < 0 || k < 32 || (k & 31)) return MV_E_SHAPE;
+  if (!mv_aligned16(w) || !mv_aligned16(w_packed)) return MV_E_ALIGN;
+  const int64_t chunks = (int64_t)((n + 15) / 16) * (k / 32) * 64;
+  hipLaunchKernelGGL(pack_weight_kernel<uint16_t>, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t *)w, (uint16_t *)w_packed, n, k, chunks);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_linear_mid_m(const void *x, int64_t x_stride, const void *w_packed, const void *bias, void *out,
+                               int64_t out_stride, int m, int n, int k, int dtype, int cfg, void *stream) {
+  if (m == 0 || n == 0) return MV_OK;
+  if (int e = check(x, x_stride, w_packed, out, out_stride, m, n, k, dtype)) return e;
+  if (bias && (((uintptr_t)bias) & 7u)) return MV_E_ALIGN;
+  int flags = cfg / 100;          // bench only: +100 the DMA ring without the arithmetic (out untouched), +200 K rotation
+  cfg %= 100;
+  if (cfg < 0 || cfg >= kNumCfgs || flags > 3) return MV_E_RANGE;
+  if (cfg == 0) cfg = auto_cfg(m, n, k, false);
+  MidParams p{x, w_packed, bias, out, x_stride, out_stride, m, n, k, 0, 0, 0, (flags & 2) ? 1 : 0};
+  if (flags & 1)
+    return dtype == MV_BF16 ? launch_cfg<bf16_tag, EPI_INGEST>(p, cfg, 1, (hipStream_t)stream) : MV_E_DTYPE;
+  return dtype == MV_BF16 ? launch_cfg<bf16_tag, EPI_PLAIN>(p, cfg, 1, (hipStream_t)stream)
+                          : launch_cfg<f16_tag, EPI_PLAIN>(p, cfg, 1, (hipStream_t)stream);
+}
+
+extern "C" int mv_gate_up_silu_mid_m(const void *x, int64_t x_stride, const void *w_gate_up_packed, void *out,
+                                     int64_t out_stride, int m, int n_inter, int k, int dtype, int cfg,
+                                     void *stream) {
+  if (m == 0 || n_inter == 0) return MV_OK;
+  if (int e = check(x, x_stride, w_gate_up_packed, out, out_stride, m, n_inter, k, dtype)) return e;
+  if (n_inter & 15) return MV_E_SHAPE;
+  if (cfg < 0 || cfg >= kNumCfgs) return MV_E_RANGE;
+  if (cfg == 0) cfg = auto_cfg(m, n_inter, k, true);
+  if (!kCfgs[cfg].gated_ok) return MV_E_RANGE;
+  MidParams p{x, w_gate_up_packed, nullptr, out, x_stride, out_stride, m, n_inter, k, 0, 0, 0, 0};
+  return dtype == MV_BF16 ? launch_cfg<bf16_tag, EPI_GATED>(p, cfg, 1, (hipStream_t)stream)
+                          : launch_cfg<f16_tag, EPI_GATED>(p, cfg, 1, (hipStream_t)stream);
+}
+
+// fp32 partial sums of a K split: out_partial [splits][M][N] (row stride n), no bias, no rounding.
+extern "C" int mv_linear_mid_m_partial(const void *x, int64_t x_stride, const void *w_packed, float *out_partial, int m,
+                                       int n, int k, int splits, int dtype, int cfg, void *stream) {
+  if (m == 0 || n == 0) return MV_OK;
+  if (int e = check(x, x_stride, w_packed, out_partial, n, m, n, k, dtype)) return e;
+  if (!mv_aligned16(out_partial)) return MV_E_ALIGN;
+  if (splits < 1 || splits > 16 || cfg < 0 || cfg >= kNumCfgs) return MV_E_RANGE;
+  if (cfg == 0) cfg = auto_cfg(m, n * splits, k, false);
+  MidParams p{x, w_packed, nullptr, out_partial, x_stride, n, m, n, k, 0, 0, 0, 0};
+  return dtype == MV_BF16 ? launch_cfg<bf16_tag, EPI_PARTIAL>(p, cfg, splits, (hipStream_t)stream)
+                          : launch_cfg<f16_tag, EPI_PARTIAL>(p, cfg, splits, (hipStream_t)stream);
+}

@@ -40,12 +40,15 @@ __device__ __forceinline__ float block_sum(float x, float *red) {
 }
 
 // MAXV = 16-byte vectors per thread held in registers.
-template <typename Tag, int MAXV, bool ADD>
+// PARTIAL: x is not a [rows, cols] tensor of dtype but `splits` fp32 partial sums [splits][rows][cols] of a
+// K-split projection (mv_linear_mid_m_partial): they are summed in split order and rounded to dtype first —
+// the rounding point of the GEMM whose output the reference's add_rms_forward reads.
+template <typename Tag, int MAXV, bool ADD, bool PARTIAL = false>
 __global__ void rmsnorm_kernel(const typename elem<Tag>::T *__restrict__ x, int64_t x_stride,
                                typename elem<Tag>::T *residual, int64_t res_stride,
                                const typename elem<Tag>::T *__restrict__ w,
                                typename elem<Tag>::T *__restrict__ out, int64_t out_stride,
-                               int cols, float eps) {
+                               int cols, float eps, const float *__restrict__ partial = nullptr, int splits = 0) {
   constexpr int VEC = elem<Tag>::VEC;
   __shared__ float red[16];
   const int row = blockIdx.x;
@@ -59,7 +62,25 @@ __global__ void rmsnorm_kernel(const typename elem<Tag>::T *__restrict__ x, int6
     const int c = threadIdx.x + i * blockDim.x;
     if (c < nvec) {
       wraw[i] = *reinterpret_cast<const u32x4 *>(w + c * VEC);  // not a second round trip after the reduction
-      load_vec<Tag>(xr + c * VEC, vals[i]);
+      if constexpr (PARTIAL) {
+        static_assert(!PARTIAL || VEC == 8, "partial sums feed 16-bit outputs");
+        const float *pp = partial + (int64_t)row * cols + c * VEC;
+        const int64_t sstride = (int64_t)gridDim.x * cols;
+        f32x4 lo = *reinterpret_cast<const f32x4 *>(pp), hi = *reinterpret_cast<const f32x4 *>(pp + 4);
+        for (int sp = 1; sp < splits; ++sp) {
+          const f32x4 l2 = *reinterpret_cast<const f32x4 *>(pp + sp * sstride);
+          const f32x4 h2 = *reinterpret_cast<const f32x4 *>(pp + sp * sstride + 4);
+          lo += l2;
+          hi += h2;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vals[i][j] = elem<Tag>::ld(elem<Tag>::st(lo[j]));
+          vals[i][4 + j] = elem<Tag>::ld(elem<Tag>::st(hi[j]));
+        }
+      } else {
+        load_vec<Tag>(xr + c * VEC, vals[i]);
+      }
       if constexpr (ADD) {
         typename elem<Tag>::T *rr = residual + (int64_t)row * res_stride + c * VEC;
         float r[VEC];
@@ -143,6 +164,41 @@ extern "C" int mv_add_rmsnorm(const void *x, int64_t x_stride, void *residual, i
   MV_DISPATCH_DTYPE(dtype, return (launch_rmsnorm<Tag, true>(x, x_stride, residual, res_stride, w, out,
                                                              out_stride, rows, cols, eps,
                                                              (hipStream_t)stream)));
+  return MV_OK;
+}
+
+// K6 behind a K-split projection: see rmsnorm_kernel<PARTIAL>.
+extern "C" int mv_add_rmsnorm_partial(const float *partial, int splits, void *residual, int64_t res_stride,
+                                      const void *w, void *out, int64_t out_stride, int rows, int cols,
+                                      float eps, int dtype, void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!partial || !w || !out || !residual) return MV_E_NULLPTR;
+  if (rows < 0 || cols <= 0 || (cols & 7) || splits < 1 || splits > 16) return MV_E_SHAPE;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (!mv_aligned16(partial) || !mv_aligned16(w) || !mv_aligned16(out) || !mv_aligned16(residual) ||
+      (out_stride & 7) || (res_stride & 7))
+    return MV_E_ALIGN;
+  const int nvec = cols / 8;
+  int threads = (nvec + 63) / 64 * 64;
+  if (threads > 256) threads = nvec > 1024 ? 1024 : 256;
+  const int per_thread = (nvec + threads - 1) / threads;
+#define MV_RMSP_LAUNCH(TAG, MV)                                                                              \
+  hipLaunchKernelGGL((rmsnorm_kernel<TAG, MV, true, true>), dim3(rows), dim3(threads), 0, (hipStream_t)stream, \
+                     (const uint16_t *)nullptr, (int64_t)0, (uint16_t *)residual, res_stride, (const uint16_t *)w, \
+                     (uint16_t *)out, out_stride, cols, eps, partial, splits)
+#define MV_RMSP_DISPATCH(TAG)                 \
+  do {                                        \
+    if (per_thread <= 1) MV_RMSP_LAUNCH(TAG, 1);      \
+    else if (per_thread <= 2) MV_RMSP_LAUNCH(TAG, 2); \
+    else if (per_thread <= 4) MV_RMSP_LAUNCH(TAG, 4); \
+    else if (per_thread <= 8) MV_RMSP_LAUNCH(TAG, 8); \
+    else return MV_E_SHAPE;                   \
+  } while (0)
+  if (dtype == MV_BF16) MV_RMSP_DISPATCH(bf16_tag);
+  else MV_RMSP_DISPATCH(f16_tag);
+#undef MV_RMSP_DISPATCH
+#undef MV_RMSP_LAUNCH
+  MV_LAUNCH_CHECK();
   return MV_OK;
 }
 

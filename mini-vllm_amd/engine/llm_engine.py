@@ -38,7 +38,16 @@ def _worker_main(config: Config, rank: int) -> None:
         if cmd[0] == "exit":
             break
         if cmd[0] == "generate":
-            engine._generate_local(cmd[1], cmd[2], use_tqdm=False)
+            try:
+                engine._generate_local(cmd[1], cmd[2], use_tqdm=False)
+            except Exception:
+                # the driver validated the request before telling us, so this is a real fault: say so and leave
+                # with a non-zero code (the driver sees the dead worker and stops using the collective group)
+                logger.exception("tensor-parallel worker %d failed inside generate()", rank)
+                try:
+                    engine.model_runner.exit()
+                finally:
+                    os._exit(1)
     engine.model_runner.exit()
 
 
@@ -103,19 +112,28 @@ class LLMEngine:
         self.ps.clear()
 
     # ------------------------------------------------------------------ requests
-    def add_request(self, prompt: str | list[int], sampling_params: SamplingParams | None = None) -> int:
-        if sampling_params is None:
-            sampling_params = SamplingParams()
+    def _validate_prompt(self, prompt: str | list[int]) -> list[int]:
+        """Token ids of a prompt that one prefill can take, or an exception.  The ONE check behind both
+        ``add_request`` and the tensor-parallel driver's pre-validation (a request that would make a rank raise
+        half-way through must fail before the workers are told)."""
         if isinstance(prompt, str):
             if self.tokenizer is None:
                 raise RuntimeError("no tokenizer loaded: pass prompts as lists of token ids")
             prompt = self.tokenizer.encode(prompt)
+        if not prompt:
+            raise ValueError("token_ids must contain at least one token")
         limit = min(self.config.max_num_batched_tokens, self.config.max_model_len)
         if self.config.num_kvcache_blocks > 0:   # (-1 before the KV cache is sized)
             limit = min(limit, self.config.num_kvcache_blocks * self.config.kvcache_block_size)
         if len(prompt) > limit:
             # beyond the reference, whose scheduler only notices when nothing can be scheduled any more
             raise ValueError(f"prompt of {len(prompt)} tokens exceeds what one prefill can take (max_num_batched_tokens, max_model_len, KV pool): {limit}")
+        return prompt
+
+    def add_request(self, prompt: str | list[int], sampling_params: SamplingParams | None = None) -> int:
+        if sampling_params is None:
+            sampling_params = SamplingParams()
+        prompt = self._validate_prompt(prompt)
         seq = Sequence(prompt, sampling_params, block_size=self.config.kvcache_block_size)
         self.scheduler.add(seq)
         return seq.seq_id
@@ -138,20 +156,14 @@ class LLMEngine:
         return self.scheduler.is_finished()
 
     def generate(self, prompts, sampling_params=None, use_tqdm: bool = True):
+        # the WHOLE list is validated (and tokenized) before anything is enqueued or any worker is told: a bad
+        # prompt in the middle must not leave its predecessors queued in the scheduler, nor kill a worker
+        if isinstance(sampling_params, list) and len(sampling_params) != len(prompts):
+            raise ValueError("Length of sampling_params list must match prompts")
+        prompts = [self._validate_prompt(p) for p in prompts]
         if self._is_driver:
-            if self.tokenizer is not None:   # ship token ids: workers need no tokenizer round trip
-                prompts = [self.tokenizer.encode(p) if isinstance(p, str) else p for p in prompts]
-            # whatever would make a rank raise half-way through must fail HERE, before the workers are told
-            if isinstance(sampling_params, list) and len(sampling_params) != len(prompts):
-                raise ValueError("Length of sampling_params list must match prompts")
-            for p in prompts:
-                if isinstance(p, str):
-                    raise RuntimeError("no tokenizer loaded: pass prompts as lists of token ids")
-                if not p:
-                    raise ValueError("token_ids must contain at least one token")
-                if len(p) > min(self.config.max_num_batched_tokens, self.config.max_model_len):
-                    # (single process: the scheduler raises "No sequences scheduled" for it, like the reference)
-                    raise ValueError(f"prompt of {len(p)} tokens exceeds max_num_batched_tokens / max_model_len")
+            if any(not p.is_alive() for p in self.ps):
+                raise RuntimeError("a tensor-parallel worker process has died: this engine cannot serve any more")
             self.model_runner.distributed_manager.broadcast_data(("generate", prompts, sampling_params), src=0)
         return self._generate_local(prompts, sampling_params, use_tqdm)
 

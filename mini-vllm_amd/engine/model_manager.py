@@ -65,8 +65,11 @@ class ModelManager:
             if os.path.isdir(self.config.model) and not any(
                     os.path.exists(os.path.join(self.config.model, f)) for f in files):
                 raise FileNotFoundError(f"no tokenizer files in {self.config.model}")
-            tok = AutoTokenizer.from_pretrained(self.config.model, trust_remote_code=True, use_fast=True,
-                                                local_files_only=True)
+            # custom tokenizer code in the model directory runs only if the user asked for it (the reference
+            # hard-codes True, models/manager.py:99)
+            tok = AutoTokenizer.from_pretrained(self.config.model,
+                                                trust_remote_code=bool(self.config.trust_remote_code),
+                                                use_fast=True, local_files_only=True)
             if tok.pad_token is None:
                 tok.pad_token = tok.eos_token
             self.tokenizer = tok
@@ -95,6 +98,12 @@ class ModelManager:
         # params already have `dtype`; this also casts the RoPE tables like the reference's
         # model.to(device, dtype) does (its bf16 runs rotate with bf16-rounded cos/sin)
         self.model = model.to(device=self.device, dtype=dtype)
+        # decode batches of 17..512 rows stream a fragment-ordered copy of every projection weight
+        # (layers/linear.py); MV_PACK_WEIGHTS=0 keeps only the row-major weights (library GEMMs above 16-32 rows)
+        if os.environ.get("MV_PACK_WEIGHTS", "1") != "0" and cfg.max_num_seqs > 16:
+            for mod in self.model.modules():
+                if hasattr(mod, "pack_for_decode"):
+                    mod.pack_for_decode()
 
     @staticmethod
     def _dummy_init(model, seed: int) -> None:

@@ -17,7 +17,7 @@ from torch import nn
 from .. import hip_ops
 from ..layers import (Attention, MergedColumnParallelLinear, ParallelLMHead, QKVParallelLinear, RMSNorm,
                       RowParallelLinear, SiluAndMul, VocabParallelEmbedding, get_rope)
-from ..layers.linear import small_m
+from ..layers.linear import mid_m, mid_plan, small_m
 from ..parallel_state import get_tensor_parallel_world_size, tp_all_reduce_add_rmsnorm
 from ..utils.context import get_context
 
@@ -101,8 +101,8 @@ class QwenAttention(nn.Module):
             attn.k_cache if has_cache else None, attn.v_cache if has_cache else None,
             ctx.slot_mapping if has_cache else None, want_k_out=want_k)
         o = attn(q_rot, k_rot, v, kv_stored=True)
-        out = self.o_proj(o.view(t, self.q_size), reduce=reduce)
-        return out.view(*lead, out.shape[-1])
+        out = self.o_proj(o.view(t, self.q_size), reduce=reduce, partial_ok=len(lead) == 1)
+        return out if hasattr(out, "to_tensor") else out.view(*lead, out.shape[-1])
 
     def extra_repr(self) -> str:
         return (f"num_heads={self.num_heads}, num_kv_heads={self.num_kv_heads}, head_dim={self.head_dim}, "
@@ -120,10 +120,17 @@ class QwenMLP(nn.Module):
         self.hidden_act, self.intermediate_size, self.hidden_size = hidden_act, intermediate_size, hidden_size
 
     def forward(self, x, reduce: bool = True):
-        w = self.gate_up_proj.weight
+        w, gu = self.gate_up_proj.weight, self.gate_up_proj
+        flat = x.dim() == 2
         if small_m(x, w):  # decode-sized batch: SiluAndMul in the epilogue of the weight-streaming gate_up kernel
-            return self.down_proj(hip_ops.gate_up_silu_small_m(x, w), reduce=reduce)
-        return self.down_proj(self.act_fn(self.gate_up_proj(x)), reduce=reduce)
+            return self.down_proj(hip_ops.gate_up_silu_small_m(x, w), reduce=reduce, partial_ok=flat)
+        n_inter = w.shape[0] // 2
+        if mid_m(x, gu.weight_packed) and n_inter % 16 == 0 and hip_ops.linear_mid_m_ok(x, n_inter):
+            cfg, _ = mid_plan("gated", x.numel() // x.shape[-1], n_inter, w.shape[1])
+            if cfg:
+                act = hip_ops.gate_up_silu_mid_m(x, gu.weight_packed, n_inter, cfg)
+                return self.down_proj(act, reduce=reduce, partial_ok=flat)
+        return self.down_proj(self.act_fn(self.gate_up_proj(x)), reduce=reduce, partial_ok=flat)
 
 
 class QwenDecoderLayer(nn.Module):

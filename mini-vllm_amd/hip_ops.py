@@ -29,6 +29,8 @@ _SIGNATURES = {
                            c_int, c_void_p]),
     "mv_add_rmsnorm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                c_int, c_int, c_float, c_int, c_void_p]),
+    "mv_add_rmsnorm_partial": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                       c_float, c_int, c_void_p]),
     "mv_rope_qk_store": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
                                  c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
@@ -51,6 +53,14 @@ _SIGNATURES = {
                                   c_int, c_int, c_void_p]),
     "mv_gate_up_silu_small_m": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                         c_int, c_void_p]),
+    "mv_packed_weight_elems": (c_size_t, [c_int, c_int]),
+    "mv_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mv_linear_mid_m": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                c_int, c_int, c_int, c_void_p]),
+    "mv_gate_up_silu_mid_m": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                      c_int, c_int, c_void_p]),
+    "mv_linear_mid_m_partial": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_int, c_int, c_void_p]),
     "mv_ar_region_bytes": (c_size_t, [c_size_t]),
     "mv_ar_max_world": (c_int, []),
     "mv_ar_alloc": (c_int, [c_size_t, c_void_p]),
@@ -202,6 +212,22 @@ def add_rmsnorm(x, residual, weight, eps: float, inplace: bool = True):
                                out.data_ptr(), out.stride(0), x2.shape[0], cols, float(eps), _dt(x),
                                _stream()), "mv_add_rmsnorm")
     return out.view(x.shape), res.view(residual.shape)
+
+
+def add_rmsnorm_partial(partial, residual, weight, eps: float):
+    """``add_rmsnorm`` whose x is the sum of fp32 K-split partials [S, rows, cols] (linear_mid_m_partial);
+    residual is updated in place.  Returns (normed, residual)."""
+    _need_cuda(partial, residual, weight)
+    s, rows, cols = partial.shape
+    if partial.dtype != torch.float32 or not partial.is_contiguous() or not residual.is_contiguous():
+        raise MvHipError("partial sums must be contiguous fp32, the residual contiguous")
+    r2 = residual.view(-1, cols)
+    out = torch.empty((rows, cols), dtype=residual.dtype, device=residual.device)
+    w = weight if weight.dtype == residual.dtype else weight.to(residual.dtype)
+    _check(_lib.mv_add_rmsnorm_partial(partial.data_ptr(), s, r2.data_ptr(), r2.stride(0), w.data_ptr(),
+                                       out.data_ptr(), out.stride(0), rows, cols, float(eps), _dt(residual),
+                                       _stream()), "mv_add_rmsnorm_partial")
+    return out.view(residual.shape), residual
 
 
 # ---------------------------------------------------------------- K7
@@ -378,6 +404,65 @@ def gate_up_silu_small_m(x, weight):
                                         out.stride(0), x2.shape[0], n, k, _dt(x), _stream()),
            "mv_gate_up_silu_small_m")
     return out.view(*x.shape[:-1], n)
+
+
+# ---------------------------------------------------------------- K11
+def pack_weight(weight):
+    """[N, K] row-major -> the fragment-ordered copy mv_linear_mid_m streams ([ceil(N/16), K/32, 64, 8])."""
+    _need_cuda(weight)
+    n, k = weight.shape
+    if not weight.is_contiguous():
+        weight = weight.contiguous()
+    out = torch.empty((int(_lib.mv_packed_weight_elems(n, k)),), dtype=weight.dtype, device=weight.device)
+    _check(_lib.mv_pack_weight(weight.data_ptr(), out.data_ptr(), n, k, _dt(weight), _stream()), "mv_pack_weight")
+    return out.view((n + 15) // 16, k // 32, 64, 8)
+
+
+def linear_mid_m_ok(x, n: int) -> bool:
+    """True when mv_linear_mid_m takes this shape (else the caller uses the library GEMM)."""
+    k = x.shape[-1]
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and k % 64 == 0 and k >= 64
+            and x.numel() // k > 0 and n % 4 == 0 and x.stride(-1) == 1 and x.data_ptr() % 16 == 0
+            and (x.dim() != 2 or x.stride(0) % 8 == 0))
+
+
+def linear_mid_m(x, w_packed, n: int, bias=None, cfg: int = 0, out=None):
+    """x [..., K], w_packed = pack_weight(W [n, K]), bias [n] | None -> [..., n]; fp32 accumulation."""
+    _need_cuda(x, w_packed)
+    x2, k = _rows2d(x)
+    if w_packed.numel() != ((n + 15) // 16) * 16 * k or w_packed.dtype != x.dtype:
+        raise ValueError(f"packed weight of {w_packed.numel()} elements does not match [{n}, {k}]")
+    if bias is not None and (bias.dtype != x.dtype or bias.shape[0] != n):
+        raise ValueError("bias dtype/shape mismatch")
+    if out is None:
+        out = torch.empty((x2.shape[0], n), dtype=x.dtype, device=x.device)
+    _check(_lib.mv_linear_mid_m(x2.data_ptr(), x2.stride(0), w_packed.data_ptr(), _ptr(bias), out.data_ptr(),
+                                out.stride(0), x2.shape[0], n, k, _dt(x), int(cfg), _stream()), "mv_linear_mid_m")
+    return out.view(*x.shape[:-1], n)
+
+
+def gate_up_silu_mid_m(x, w_packed, n_inter: int, cfg: int = 0):
+    """x [..., K], w_packed = pack_weight([gate rows ; up rows] of shape [2I, K]) -> silu(x Wg^T) * (x Wu^T)."""
+    _need_cuda(x, w_packed)
+    x2, k = _rows2d(x)
+    if w_packed.numel() != 2 * n_inter * k or n_inter % 16:
+        raise ValueError(f"packed weight of {w_packed.numel()} elements is not a merged [2*{n_inter}, {k}] matrix")
+    out = torch.empty((x2.shape[0], n_inter), dtype=x.dtype, device=x.device)
+    _check(_lib.mv_gate_up_silu_mid_m(x2.data_ptr(), x2.stride(0), w_packed.data_ptr(), out.data_ptr(),
+                                      out.stride(0), x2.shape[0], n_inter, k, _dt(x), int(cfg), _stream()),
+           "mv_gate_up_silu_mid_m")
+    return out.view(*x.shape[:-1], n_inter)
+
+
+def linear_mid_m_partial(x, w_packed, n: int, splits: int, cfg: int = 0):
+    """fp32 partial sums [splits, M, n] of x @ W^T over `splits` K slices."""
+    _need_cuda(x, w_packed)
+    x2, k = _rows2d(x)
+    out = torch.empty((splits, x2.shape[0], n), dtype=torch.float32, device=x.device)
+    _check(_lib.mv_linear_mid_m_partial(x2.data_ptr(), x2.stride(0), w_packed.data_ptr(), out.data_ptr(),
+                                        x2.shape[0], n, k, int(splits), _dt(x), int(cfg), _stream()),
+           "mv_linear_mid_m_partial")
+    return out
 
 
 # ---------------------------------------------------------------- f2

@@ -28,6 +28,10 @@ class RMSNorm(nn.Module):
         return hip_ops.add_rmsnorm(x, residual, self.weight, self.eps, inplace=True)
 
     def forward(self, x, residual=None):
+        if hasattr(x, "to_tensor"):   # layers.linear.PartialSum: K-split partial sums of the projection in front
+            if residual is not None and residual.is_contiguous():
+                return hip_ops.add_rmsnorm_partial(x.data, residual, self.weight, self.eps)
+            x = x.to_tensor()
         if residual is None:
             return self.rms_forward(x), None
         return self.add_rms_forward(x, residual)

@@ -463,6 +463,85 @@ def test_gate_up_silu_small_m(H, dtype, m, inter, k):
     assert exact_gu.shape == (m, 2 * inter)
 
 
+# ------------------------------------------------------------------ K11
+def test_pack_weight_is_the_documented_permutation(H):
+    # [N,K] -> [ceil(N/16)][K/32][64 lanes][8]: lane l holds W[16*i + (l & 15)][32*j + 8*(l >> 4) ..+8]; rows >= N zero
+    for n, k in ((48, 64), (40, 96), (1280, 256)):
+        w = _randn(n, k, dtype=torch.bfloat16, seed=n).to(DEV)
+        p = H.pack_weight(w)
+        npad = (n + 15) // 16 * 16
+        assert p.shape == (npad // 16, k // 32, 64, 8)
+        back = p.view(npad // 16, k // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(npad, k)
+        assert torch.equal(back[:n], w) and back[n:].abs().sum() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k,bias", [
+    (256, 4096, 2048, False), (256, 4608, 3584, True), (256, 2048, 6144, False), (200, 1000, 512, True),
+    (64, 12288, 1024, False), (17, 2064, 128, False), (129, 8192 + 16, 64, True), (512, 1280, 8192, True),
+])
+def test_linear_mid_m_every_tile(H, dtype, m, n, k, bias):
+    # fp32 accumulation of 16-bit products, one rounding: within 1 ulp of the exact (float64) result, for every
+    # workgroup tile of the table (ragged row / column tiles, K loops shorter than the rings, rotated K order)
+    x = _randn(m, k, dtype=dtype, seed=m + n).to(DEV)
+    w = (_randn(n, k, dtype=torch.float32, seed=n + k) * k ** -0.5).to(dtype).to(DEV)
+    b = _randn(n, dtype=dtype, seed=3).to(DEV) if bias else None
+    exact = O.linear(x.cpu(), w.cpu(), None if b is None else b.cpu())
+    wp = H.pack_weight(w)
+    for cfg in range(0, 11):
+        got = H.linear_mid_m(x, wp, n, b, cfg=cfg)
+        assert got.shape == (m, n) and got.dtype == dtype
+        ok, worst = _ulp_ok(got.cpu(), exact, dtype, 1.0)
+        assert ok, (cfg, worst)
+    # strided input rows (a column block of a wider activation)
+    wide = torch.zeros(m, k + 64, dtype=dtype, device=DEV)
+    wide[:, 32:32 + k] = x
+    assert torch.equal(H.linear_mid_m(wide[:, 32:32 + k], wp, n, b, cfg=1), H.linear_mid_m(x, wp, n, b, cfg=1))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,inter,k", [(256, 6144, 2048), (128, 18944, 512), (40, 1008, 256), (256, 3696, 1024)])
+def test_gate_up_silu_mid_m(H, dtype, m, inter, k):
+    x = _randn(m, k, dtype=dtype, seed=m).to(DEV)
+    w = (_randn(2 * inter, k, dtype=torch.float32, seed=inter) * k ** -0.5).to(dtype).to(DEV)
+    wp = H.pack_weight(w)
+    want = O.gate_up_silu(x.cpu(), w.cpu(), dtype).double()
+    for cfg in (0, 1, 3, 5, 6, 7, 8, 10):
+        got = H.gate_up_silu_mid_m(x, wp, inter, cfg=cfg)
+        assert got.shape == (m, inter)
+        # the fused epilogue IS the unfused pair: same GEMM (checked to 1 ulp of the exact product above), same
+        # rounding points -> bit-identical to mv_linear_mid_m + mv_silu_and_mul
+        assert torch.equal(got, H.silu_and_mul(H.linear_mid_m(x, wp, 2 * inter, cfg=cfg))), cfg
+        # against the oracle (GEMM rounded from the exact product): a gate within 1 ulp of a rounding boundary
+        # may round the other way, and silu's elasticity 1 + x(1 - sigmoid(x)) amplifies that where the gate is
+        # negative; outputs there are tiny, so the bound is a few ulp of the output scale
+        ok, worst = _ulp_ok(got.cpu(), want, dtype, 8.0)
+        assert ok, (cfg, worst)
+    with pytest.raises(H.MvHipError):
+        H.gate_up_silu_mid_m(x, wp, inter, cfg=2)   # a tile whose waves do not hold gate/up pairs
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k,splits", [(256, 2048, 6144, 2), (256, 3584, 2048, 4), (100, 1000, 1024, 4), (64, 512, 192, 2)])
+def test_split_k_partials_and_the_norm_behind_them(H, dtype, m, n, k, splits):
+    x = _randn(m, k, dtype=dtype, seed=m).to(DEV)
+    w = (_randn(n, k, dtype=torch.float32, seed=n) * k ** -0.5).to(dtype).to(DEV)
+    res = _randn(m, n, dtype=dtype, seed=5).to(DEV)
+    nw = (1 + 0.1 * _randn(n, dtype=torch.float32, seed=6)).to(dtype).to(DEV)
+    wp = H.pack_weight(w)
+    exact = O.linear(x.cpu(), w.cpu())
+    for cfg in (0, 1, 6, 10):
+        part = H.linear_mid_m_partial(x, wp, n, splits, cfg=cfg)
+        assert part.shape == (splits, m, n) and part.dtype == torch.float32
+        assert (part.double().sum(0).cpu() - exact).abs().max() < 1e-4 * max(1.0, exact.abs().max())
+        # the consumer: sum in split order, ONE rounding to dtype (the GEMM's), then add + norm exactly as
+        # mv_add_rmsnorm does on that rounded tensor
+        y_ref, r_ref = H.add_rmsnorm(part.sum(0).to(dtype) if splits == 2 else
+                                     (((part[0] + part[1]) + part[2]) + part[3]).to(dtype), res.clone(), nw, 1e-6)
+        y, r = H.add_rmsnorm_partial(part, res.clone(), nw, 1e-6)
+        assert torch.equal(r, r_ref) and torch.equal(y, y_ref)
+
+
 def test_linear_small_m_argument_errors(H):
     x = torch.zeros(4, 256, dtype=torch.bfloat16, device=DEV)
     w = torch.zeros(64, 256, dtype=torch.bfloat16, device=DEV)
