@@ -10,8 +10,9 @@
  * Conventions (all entry points):
  *   - return 0 on success, <0 for an argument error (MV_E_*), >0 = hipError_t
  *   - no allocation, no host<->device sync, no host reads of device memory,
- *     no global state: every launch goes to the caller's `stream`
- *     (a hipStream_t) and is hipGraph-capturable
+ *     no global state and no environment variables: every launch goes to the
+ *     caller's `stream` (a hipStream_t) and is hipGraph-capturable; tuning
+ *     overrides are explicit `flags` / `shape` / `cfg` arguments (0 = default)
  *   - pointers are device pointers (tensor.data_ptr()); strides are in ELEMENTS
  *   - `dtype` selects the element type of activations, KV cache and weights
  *   - index tensors: slot_mapping / block_tables / context_lens / cu_seqlens
@@ -106,16 +107,23 @@ int mv_rope_qk_store(const void *q, const void *k, const void *v,
  * (page_attention.py:62-65).  Block ids outside [0,num_blocks) inside the
  * context contribute nothing (reference: zero K/V rows).
  * workspace: mv_paged_decode_workspace_bytes() bytes, 16-byte aligned. */
+/* `flags` (same value for the size query and the call), 0 = kernel variant chosen from the shape: */
+enum {
+  MV_DECODE_VECTOR = 1,   /* never the matrix-core kernel                              */
+  MV_DECODE_MFMA = 2,     /* the matrix-core kernel wherever it takes the shape        */
+  MV_DECODE_KLDS_OFF = 4, /* matrix-core kernel: K straight to registers               */
+  MV_DECODE_KLDS_ON = 8   /* matrix-core kernel: K through LDS                         */
+};
 size_t mv_paged_decode_workspace_bytes(int batch, int n_heads, int n_kv_heads,
                                        int head_dim, int block_size,
-                                       int max_blocks);
+                                       int max_blocks, int flags);
 int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *k_cache,
                     const void *v_cache, const int32_t *block_tables,
                     int64_t table_stride, const int32_t *context_lens,
                     void *out, int batch, int n_heads, int n_kv_heads,
                     int head_dim, int block_size, int max_blocks,
                     int64_t num_blocks, float scale, void *workspace,
-                    size_t ws_bytes, int dtype, void *stream);
+                    size_t ws_bytes, int dtype, int flags, void *stream);
 
 /* K2 — packed varlen causal prefill attention (flash-style, MFMA).
  * Replaces flash_attn_varlen_func / Attention._fallback_attention
@@ -126,7 +134,9 @@ int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *k_cache,
  *   paged:      k_cache/v_cache + block_tables (prefix-cache hit; keys of
  *               sequence i are its first seqlen_k tokens in the cache)
  * Causal mask is bottom-right aligned: query j of sequence i (0-based in its
- * seqlen_q) attends keys 0 .. seqlen_k-seqlen_q+j (attention.py:584-588). */
+ * seqlen_q) attends keys 0 .. seqlen_k-seqlen_q+j (attention.py:584-588).
+ * flags: MV_PREFILL_SIMPLE routes 16-bit tensors through the vector-ALU kernel (debug aid); 0 = default. */
+enum { MV_PREFILL_SIMPLE = 1 };
 int mv_prefill_varlen(const void *q, int64_t q_stride_tok, const void *k,
                       const void *v, int64_t k_stride_tok, int64_t v_stride_tok,
                       const void *k_cache, const void *v_cache,
@@ -135,7 +145,7 @@ int mv_prefill_varlen(const void *q, int64_t q_stride_tok, const void *k,
                       const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
                       int n_seqs, int max_seqlen_q, int max_seqlen_k,
                       int n_heads, int n_kv_heads, int head_dim,
-                      int block_size, float scale, int dtype, void *stream);
+                      int block_size, float scale, int dtype, int flags, void *stream);
 
 /* K8 — fused temperature / top-k / top-p / min-p / multinomial sampler.
  * Replaces Sampler.forward + sampling/functional.py:34-233,410-437 as driven
@@ -178,9 +188,11 @@ int mv_silu_and_mul(const void *x, int64_t x_stride, void *out,
  * x [M,K] row stride x_stride; w [N,K] contiguous (torch Linear layout); bias [N] or NULL;
  * out [M,N] row stride out_stride.  K % 32 == 0, N % 4 == 0; MV_E_SHAPE otherwise (and for fp32 /
  * M > 64) so that the caller can fall back to the library GEMM. */
+/* shape: launch-shape override for tools/bench_linear.py --sweep (bits 0-3 row tiles per wave, 4-8 waves,
+ * 9-10 x through LDS 1 on / 2 off, 11-12 W through LDS 1 on / 2 off); 0 = chosen from the shape. */
 int mv_linear_small_m(const void *x, int64_t x_stride, const void *w,
                       const void *bias, void *out, int64_t out_stride, int m,
-                      int n, int k, int dtype, void *stream);
+                      int n, int k, int dtype, int shape, void *stream);
 
 /* K10 + K9 — decode-sized gate_up projection with SiluAndMul in its epilogue:
  * out[m, j] = silu(x[m,:] . Wg[j,:]) * (x[m,:] . Wu[j,:]),  w_gate_up = [Wg ; Wu] of shape [2*n_inter, K]
@@ -189,7 +201,7 @@ int mv_linear_small_m(const void *x, int64_t x_stride, const void *w,
  * both GEMM outputs, silu and the product are each rounded to dtype.  Same limits as mv_linear_small_m. */
 int mv_gate_up_silu_small_m(const void *x, int64_t x_stride, const void *w_gate_up,
                             void *out, int64_t out_stride, int m, int n_inter,
-                            int k, int dtype, void *stream);
+                            int k, int dtype, int shape, void *stream);
 
 /* K11 — decode-batch linear layer for 17..512 rows (the headline batch, max_num_seqs = 256): same contract as
  * mv_linear_small_m (fp32 accumulation, bias in fp32, one rounding) with K % 64 == 0, N % 4 == 0.  Replaces the

@@ -18,8 +18,6 @@
 // applies SiluAndMul with the rounding points of the unfused pair (GEMM output -> dtype, silu -> dtype,
 // product -> dtype), so the activation never exists as a [M, 2I] tensor and one launch disappears.
 // No workspace, no atomics, no inter-workgroup traffic: hipGraph-capturable as is.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -237,14 +235,9 @@ int launch(const LinearParams &p, int rpw, int mt, dim3 grid, dim3 block, size_t
   return launch_mt_<Tag, 1, GATED, XLDS>(p, mt, grid, block, lds, stream);
 }
 
-// MV_LINEAR_RPW / MV_LINEAR_WAVES override the launch shape, for tools/bench_linear.py --sweep only: they are
-// looked at per call (the sweep changes them between calls) iff MV_LINEAR_TUNE was set when the library loaded
-int env_int(const char *name) {
-  static const bool tuning = getenv("MV_LINEAR_TUNE") != nullptr;
-  if (!tuning) return 0;
-  const char *e = getenv(name);
-  return e ? atoi(e) : 0;
-}
+// `shape` (the last-but-one argument of the entry points) overrides the launch shape, for tools/bench_linear.py
+// --sweep: bits 0-3 rows-per-wave tiles (1, 2, 4), bits 4-8 waves, bits 9-10 x through LDS (1 on, 2 off),
+// bits 11-12 W through LDS (1 on, 2 off); 0 = everything chosen from the shape
 
 // n = output columns.  Rows per wave (RPW·16; GATED: RPW gate tiles + RPW up tiles): every workgroup
 // re-reads all of x from L2 in fragment-shaped pieces that cost the texture path as much as the weight
@@ -253,10 +246,10 @@ int env_int(const char *name) {
 // them, each slice at least one full block of k-steps (two for the last doubling).  Measured choices:
 // tools/bench_linear.py --sweep.
 template <bool GATED>
-int run(const LinearParams &p, int dtype, hipStream_t st) {
+int run(const LinearParams &p, int dtype, int shape, hipStream_t st) {
   const int m = p.M, n = p.N, mt = (m + 15) / 16, steps = p.K / 32;
   int rpw = GATED ? (m > 2 && n >= 16384 ? 2 : 1) : (m <= 2 ? 1 : (n >= 65536 ? 4 : (n >= 8192 ? 2 : 1)));
-  const int force_rpw = env_int("MV_LINEAR_RPW");
+  const int force_rpw = shape & 15;
   if (force_rpw == 1 || force_rpw == 2 || (force_rpw == 4 && !GATED)) rpw = force_rpw;
   const int na = GATED ? 2 * rpw : rpw;
   const int tiles = (n + rpw * 16 - 1) / (rpw * 16);
@@ -265,13 +258,13 @@ int run(const LinearParams &p, int dtype, hipStream_t st) {
   while (waves < 16 && tiles * waves < 2048 && waves * 2 * na * mt <= 64 &&
          steps / (waves * 2) >= (waves == 8 ? 2 * unroll : unroll))
     waves *= 2;
-  const int force_waves = env_int("MV_LINEAR_WAVES");
+  const int force_waves = (shape >> 4) & 31;
   if (force_waves >= 1 && force_waves <= 16 && force_waves * na * mt <= 64) waves = force_waves;
   while (waves > 1 && waves * na * mt > 64) waves /= 2;  // 64 KB of LDS for the partial tiles
   // x through LDS once its fragment-shaped loads weigh: from 12 rows up, unless 4 row tiles per wave already
   // amortise them (measured, tools/dbg/xlds_bench.sh: M=16 +5..17 % on the 8-34 MB layers, -15 % on the LM
   // head with RPW 4; M=32 +7..30 % everywhere; M <= 8 -1..-10 %)
-  const int force_xlds = env_int("MV_LINEAR_XLDS");
+  const int force_xlds = ((shape >> 9) & 3) == 1 ? 1 : (((shape >> 9) & 3) == 2 ? -1 : 0);
   const bool xlds = force_xlds ? force_xlds > 0 : (mt >= 2 || (m >= 12 && rpw < 4));
   const size_t xblock = (size_t)mt * 16 * unroll * 64;
   while (xlds && waves > 1 && waves * xblock > 65536) waves /= 2;
@@ -281,7 +274,7 @@ int run(const LinearParams &p, int dtype, hipStream_t st) {
   // one or two weight tiles per wave and more than one block per K slice (K >= 3584, or 6144 over 8 waves): the
   // weight block also comes in by whole-row DMA (+13..25 % on the down / Qwen2-7B qkv projections at M <= 8,
   // -5 % on single-block slices and on the LM head, tools/dbg/wlds_bench.sh); MV_LINEAR_WLDS=1/-1 forces
-  const int force_wlds = env_int("MV_LINEAR_WLDS");
+  const int force_wlds = ((shape >> 11) & 3) == 1 ? 1 : (((shape >> 11) & 3) == 2 ? -1 : 0);
   const bool wlds = force_wlds ? force_wlds > 0 : (steps / waves > unroll && n < 65536);
   if (wlds && !xlds && mt == 1 && na <= 2) {
     const size_t wblock = (size_t)na * 16 * unroll * 64;
@@ -329,17 +322,18 @@ int check(const void *x, int64_t x_stride, const void *w, const void *bias, void
 }  // namespace
 
 extern "C" int mv_linear_small_m(const void *x, int64_t x_stride, const void *w, const void *bias, void *out,
-                                 int64_t out_stride, int m, int n, int k, int dtype, void *stream) {
+                                 int64_t out_stride, int m, int n, int k, int dtype, int shape, void *stream) {
   if (m == 0 || n == 0) return MV_OK;
   if (int e = check(x, x_stride, w, bias, out, out_stride, m, n, k, dtype)) return e;
   LinearParams p{x, w, bias, out, x_stride, out_stride, m, n, k};
-  return run<false>(p, dtype, (hipStream_t)stream);
+  return run<false>(p, dtype, shape, (hipStream_t)stream);
 }
 
 extern "C" int mv_gate_up_silu_small_m(const void *x, int64_t x_stride, const void *w_gate_up, void *out,
-                                       int64_t out_stride, int m, int n_inter, int k, int dtype, void *stream) {
+                                       int64_t out_stride, int m, int n_inter, int k, int dtype, int shape,
+                                       void *stream) {
   if (m == 0 || n_inter == 0) return MV_OK;
   if (int e = check(x, x_stride, w_gate_up, nullptr, out, out_stride, m, n_inter, k, dtype)) return e;
   LinearParams p{x, w_gate_up, nullptr, out, x_stride, out_stride, m, n_inter, k};
-  return run<true>(p, dtype, (hipStream_t)stream);
+  return run<true>(p, dtype, shape, (hipStream_t)stream);
 }

@@ -24,6 +24,7 @@ struct DecodeParams {
   float scale_log2;  // softmax scale * log2(e)
 };
 
-// MFMA variant (16-bit dtypes, D = 128, >= 4 query heads per kv head); g_chunk <= 16 heads per workgroup
+// MFMA variant (16-bit dtypes, D = 128, >= 4 query heads per kv head); g_chunk <= 16 heads per workgroup;
+// klds: 1 / 0 = K through LDS or straight to registers, -1 = chosen from the grid
 int mv_paged_decode_mfma_launch(const DecodeParams &p, int n_chunks, int nsplit, int batch, int dtype,
-                                hipStream_t stream);
+                                int klds, hipStream_t stream);

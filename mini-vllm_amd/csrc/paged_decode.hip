@@ -316,16 +316,13 @@ int pick_g(int g_total) {
 }
 
 bool make_plan(int batch, int n_heads, int n_kv_heads, int head_dim, int block_size,
-               int max_blocks, int dtype, DecodePlan *pl) {
+               int max_blocks, int dtype, int flags, DecodePlan *pl) {
   if (n_kv_heads <= 0 || n_heads % n_kv_heads) return false;
   if (head_dim != 64 && head_dim != 128) return false;
   const int g_total = n_heads / n_kv_heads;
   // >= 4 query heads per kv head: QK^T and PV go to the matrix cores (the vector path spends
   // ~G x 20 VALU instructions per key and drops to 2-3.7 TB/s at G = 7..8)
-  static const int min_group = [] {  // MV_DECODE_MFMA_MIN_G: tuning override (1 = always, 99 = never)
-    const char *e = getenv("MV_DECODE_MFMA_MIN_G");
-    return e ? atoi(e) : kMfmaMinGroup;
-  }();
+  const int min_group = (flags & MV_DECODE_VECTOR) ? 1 << 30 : ((flags & MV_DECODE_MFMA) ? 1 : kMfmaMinGroup);
   pl->mfma = dtype != MV_F32 && head_dim == 128 && g_total >= min_group && block_size % 32 == 0;
   if (pl->mfma) {
     pl->g_chunk = g_total < 16 ? g_total : 16;
@@ -369,9 +366,10 @@ void launch_g(const DecodeParams &p, const DecodePlan &pl, int batch, hipStream_
 }
 
 template <typename Tag, int D>
-int launch_d(const DecodeParams &p, const DecodePlan &pl, int batch, int dtype, hipStream_t stream) {
+int launch_d(const DecodeParams &p, const DecodePlan &pl, int batch, int dtype, int flags, hipStream_t stream) {
   if (pl.mfma) {
-    const int rc = mv_paged_decode_mfma_launch(p, pl.n_chunks, pl.nsplit, batch, dtype, stream);
+    const int klds = (flags & MV_DECODE_KLDS_ON) ? 1 : ((flags & MV_DECODE_KLDS_OFF) ? 0 : -1);
+    const int rc = mv_paged_decode_mfma_launch(p, pl.n_chunks, pl.nsplit, batch, dtype, klds, stream);
     if (rc != MV_OK) return rc;
     if (pl.nsplit > 1) {
       hipLaunchKernelGGL((paged_decode_reduce_kernel<Tag, D>), dim3(batch * p.n_heads), dim3(D), 0,
@@ -403,11 +401,11 @@ int launch_d(const DecodeParams &p, const DecodePlan &pl, int batch, int dtype, 
 }  // namespace
 
 extern "C" size_t mv_paged_decode_workspace_bytes(int batch, int n_heads, int n_kv_heads,
-                                                  int head_dim, int block_size, int max_blocks) {
+                                                  int head_dim, int block_size, int max_blocks, int flags) {
   // sized for the widest element type so one buffer serves every dtype
   DecodePlan a, b;
-  if (batch <= 0 || !make_plan(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks, MV_BF16, &a) ||
-      !make_plan(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks, MV_F32, &b))
+  if (batch <= 0 || !make_plan(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks, MV_BF16, flags, &a) ||
+      !make_plan(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks, MV_F32, flags, &b))
     return 256;
   const int ns = a.nsplit > b.nsplit ? a.nsplit : b.nsplit;
   if (ns <= 1) return 256;
@@ -420,7 +418,7 @@ extern "C" int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *
                                int64_t table_stride, const int32_t *context_lens, void *out,
                                int batch, int n_heads, int n_kv_heads, int head_dim,
                                int block_size, int max_blocks, int64_t num_blocks, float scale,
-                               void *workspace, size_t ws_bytes, int dtype, void *stream) {
+                               void *workspace, size_t ws_bytes, int dtype, int flags, void *stream) {
   if (batch == 0) return MV_OK;
   if (!q || !out || !context_lens) return MV_E_NULLPTR;
   if (batch < 0 || n_heads <= 0 || block_size <= 0 || max_blocks < 0 || num_blocks < 0)
@@ -434,7 +432,7 @@ extern "C" int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *
   }
   if (!k_cache || !v_cache || !block_tables) return MV_E_NULLPTR;
   DecodePlan pl;
-  if (!make_plan(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks, dtype, &pl))
+  if (!make_plan(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks, dtype, flags, &pl))
     return MV_E_SHAPE;
   if (!mv_aligned16(q) || !mv_aligned16(k_cache) || !mv_aligned16(v_cache) || !mv_aligned16(out) ||
       (q_stride_tok * esz) % 16)
@@ -471,9 +469,9 @@ extern "C" int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *
   }
   hipStream_t st = (hipStream_t)stream;
   if (head_dim == 128) {
-    MV_DISPATCH_DTYPE(dtype, return (launch_d<Tag, 128>(p, pl, batch, dtype, st)));
+    MV_DISPATCH_DTYPE(dtype, return (launch_d<Tag, 128>(p, pl, batch, dtype, flags, st)));
   } else {
-    MV_DISPATCH_DTYPE(dtype, return (launch_d<Tag, 64>(p, pl, batch, dtype, st)));
+    MV_DISPATCH_DTYPE(dtype, return (launch_d<Tag, 64>(p, pl, batch, dtype, flags, st)));
   }
   return MV_OK;
 }

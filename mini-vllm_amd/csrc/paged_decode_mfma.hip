@@ -276,12 +276,11 @@ __global__ void __launch_bounds__(256, KLDS ? 2 : 4) paged_decode_mfma_kernel(De
 }  // namespace
 
 int mv_paged_decode_mfma_launch(const DecodeParams &p, int n_chunks, int nsplit, int batch, int dtype,
-                                hipStream_t stream) {
+                                int force, hipStream_t stream) {
   dim3 grid(p.n_kv_heads * n_chunks, nsplit, batch), block(256);
   // K through LDS pays once the (sequence, kv head) pairs alone fill the chip (whole-row DMA instead of
   // 16 rows x 64 B per load: 5.5 -> 5.9 TB/s on Qwen2-7B heads at B=256, 5.8 -> 6.4 at ctx 4096); with fewer
-  // workgroups its 2-per-CU residency (64 KiB of LDS) costs more than it gains.  MV_DECODE_MFMA_KLDS=0/1 forces.
-  static const int force = [] { const char *e = getenv("MV_DECODE_MFMA_KLDS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  // workgroups its 2-per-CU residency (64 KiB of LDS) costs more than it gains.  The caller's flags can force.
   const bool klds = force >= 0 ? force == 1 : (int64_t)grid.x * grid.z >= 1024;
   if (dtype == MV_BF16) {
     if (klds) hipLaunchKernelGGL((paged_decode_mfma_kernel<bf16_tag, true>), grid, block, 0, stream, p, n_chunks);

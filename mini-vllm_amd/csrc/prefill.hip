@@ -3,7 +3,6 @@
 //  varlen, :467-504 fallback).  Dispatches to the MFMA flash kernel for
 // 16-bit tensors and to the vector-ALU kernel otherwise.
 #include "prefill.h"
-#include <cstdlib>
 
 extern "C" int mv_prefill_varlen(const void *q, int64_t q_stride_tok, const void *k, const void *v,
                                  int64_t k_stride_tok, int64_t v_stride_tok, const void *k_cache,
@@ -12,7 +11,7 @@ extern "C" int mv_prefill_varlen(const void *q, int64_t q_stride_tok, const void
                                  const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
                                  int n_seqs, int max_seqlen_q, int max_seqlen_k, int n_heads,
                                  int n_kv_heads, int head_dim, int block_size, float scale,
-                                 int dtype, void *stream) {
+                                 int dtype, int flags, void *stream) {
   if (n_seqs == 0 || max_seqlen_q == 0) return MV_OK;
   if (!q || !out || !cu_seqlens_q || !cu_seqlens_k) return MV_E_NULLPTR;
   const bool paged = block_tables != nullptr;
@@ -40,12 +39,8 @@ extern "C" int mv_prefill_varlen(const void *q, int64_t q_stride_tok, const void
   p.table_width = paged ? (int)((max_seqlen_k + block_size - 1) / block_size) : 0;
   p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
-  // MV_PREFILL_FORCE_SIMPLE=1 routes 16-bit tensors through the vector-ALU kernel (debug aid)
-  static const bool force_simple = [] {
-    const char *e = getenv("MV_PREFILL_FORCE_SIMPLE");
-    return e && e[0] == '1';
-  }();
-  if (dtype != MV_F32 && !force_simple) {
+  // MV_PREFILL_SIMPLE routes 16-bit tensors through the vector-ALU kernel (debug aid)
+  if (dtype != MV_F32 && !(flags & MV_PREFILL_SIMPLE)) {
     const int rc = mv_prefill_mfma_launch(p, dtype, st);
     if (rc != MV_E_SHAPE) return rc;
   }

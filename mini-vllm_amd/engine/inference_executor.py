@@ -347,9 +347,10 @@ class InferenceExecutor:
         # the split-KV workspace must exist before capture (no allocation inside a graph)
         hf = self.config.hf_config
         heads = hf.num_attention_heads // get_tensor_parallel_world_size()
+        # ... sized for every batch an EAGER step can carry too (max_num_seqs may exceed the largest graph bucket)
         hip_ops.workspace(max(hip_ops.paged_decode_workspace_bytes(bs, heads, self.num_kv_heads, self.head_dim,
                                                                    self.block_size, self.max_blocks_per_seq)
-                              for bs in self.graph_bs), dev)
+                              for bs in list(self.graph_bs) + [self.config.max_num_seqs]), dev)
         self._general_capture = "no" if not general_ok else "done"
         try:
             if self.tp_size > 1:   # the family without a backend collective inside (peer-to-peer kernels only)

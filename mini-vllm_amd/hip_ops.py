@@ -35,14 +35,14 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                  c_int, c_int, c_void_p]),
-    "mv_paged_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mv_paged_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "mv_paged_decode": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                 c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_float,
-                                c_void_p, c_size_t, c_int, c_void_p]),
+                                c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "mv_prefill_varlen": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                   c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
-                                  c_void_p]),
+                                  c_int, c_void_p]),
     "mv_sample_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mv_sample": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
                           c_uint64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t,
@@ -50,9 +50,9 @@ _SIGNATURES = {
     "mv_decode_advance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mv_silu_and_mul": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "mv_linear_small_m": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
-                                  c_int, c_int, c_void_p]),
+                                  c_int, c_int, c_int, c_void_p]),
     "mv_gate_up_silu_small_m": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
-                                        c_int, c_void_p]),
+                                        c_int, c_int, c_void_p]),
     "mv_packed_weight_elems": (c_size_t, [c_int, c_int]),
     "mv_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mv_linear_mid_m": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
@@ -82,6 +82,29 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 class MvHipError(RuntimeError):
     pass
+
+
+# ---------------------------------------------------------------- tuning switches
+# The C-ABI reads no environment: the overrides below are read HERE, once, and passed as explicit arguments.
+MV_DECODE_VECTOR, MV_DECODE_MFMA, MV_DECODE_KLDS_OFF, MV_DECODE_KLDS_ON = 1, 2, 4, 8
+MV_PREFILL_SIMPLE = 1
+
+
+def _decode_flags_from_env() -> int:
+    """MV_DECODE_MFMA_MIN_G=1 / 99: matrix-core decode kernel always / never; MV_DECODE_MFMA_KLDS=0 / 1: K straight
+    to registers / through LDS.  (Bench and debugging aids; unset = the kernels choose from the shape.)"""
+    f = 0
+    g = os.environ.get("MV_DECODE_MFMA_MIN_G")
+    if g is not None:
+        f |= MV_DECODE_MFMA if int(g) <= 1 else (MV_DECODE_VECTOR if int(g) >= 17 else 0)
+    k = os.environ.get("MV_DECODE_MFMA_KLDS")
+    if k is not None:
+        f |= MV_DECODE_KLDS_ON if int(k) else MV_DECODE_KLDS_OFF
+    return f
+
+
+DECODE_FLAGS = _decode_flags_from_env()
+PREFILL_FLAGS = MV_PREFILL_SIMPLE if os.environ.get("MV_PREFILL_FORCE_SIMPLE") == "1" else 0
 
 
 def _load():
@@ -146,14 +169,19 @@ def _i32(t):
 
 # ---------------------------------------------------------------- workspace
 _workspace: dict[int, torch.Tensor] = {}
+_workspace_retired: list[torch.Tensor] = []   # outgrown buffers stay alive: captured graphs hold their pointers
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only per-device scratch buffer (allocate before graph capture)."""
+    """Grow-only per-device scratch buffer (allocate before graph capture).  A buffer that is outgrown is never
+    freed: a hipGraph captured earlier still reads and writes it (split-KV partials), and handing its memory
+    back to the caching allocator would let another tensor land under a replaying graph."""
     idx = torch.device(device).index or 0
     buf = _workspace.get(idx)
     if buf is None or buf.numel() < nbytes:
-        # generous first allocation: captured graphs hold this pointer, so it must not move later
+        if buf is not None:
+            _workspace_retired.append(buf)
+        # generous first allocation: captured graphs hold this pointer, so it should not have to move later
         buf = torch.empty(max(int(nbytes), 32 << 20), dtype=torch.uint8, device=device)
         _workspace[idx] = buf
     return buf
@@ -266,12 +294,13 @@ def rope_qk_store(q, k, v, positions, cos, sin, q_norm_w=None, k_norm_w=None, ep
 
 
 # ---------------------------------------------------------------- K3
-def paged_decode_workspace_bytes(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks) -> int:
+def paged_decode_workspace_bytes(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks,
+                                 flags: int | None = None) -> int:
     return int(_lib.mv_paged_decode_workspace_bytes(batch, n_heads, n_kv_heads, head_dim, block_size,
-                                                    max_blocks))
+                                                    max_blocks, DECODE_FLAGS if flags is None else flags))
 
 
-def paged_decode(q, k_cache, v_cache, block_tables, context_lens, scale: float, out=None):
+def paged_decode(q, k_cache, v_cache, block_tables, context_lens, scale: float, out=None, flags: int | None = None):
     """q [B,H,D]; caches [nb,bs,Hkv,D]; block_tables int [B,nblk] (row-strided view ok);
     context_lens int [B].  Returns [B,H,D] in q's dtype."""
     _need_cuda(q, k_cache, v_cache, block_tables, context_lens)
@@ -286,18 +315,19 @@ def paged_decode(q, k_cache, v_cache, block_tables, context_lens, scale: float, 
         bt = bt.contiguous()
     cl = _i32(context_lens)
     max_blocks = bt.shape[1]
-    ws_bytes = paged_decode_workspace_bytes(b, h, hkv, d, bs, max_blocks)
+    flags = DECODE_FLAGS if flags is None else flags
+    ws_bytes = paged_decode_workspace_bytes(b, h, hkv, d, bs, max_blocks, flags)
     ws = workspace(ws_bytes, q.device)
     _check(_lib.mv_paged_decode(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(),
                                 bt.data_ptr(), bt.stride(0) if max_blocks else 0, cl.data_ptr(),
                                 out.data_ptr(), b, h, hkv, d, bs, max_blocks, nb, float(scale),
-                                ws.data_ptr(), ws.numel(), _dt(q), _stream()), "mv_paged_decode")
+                                ws.data_ptr(), ws.numel(), _dt(q), flags, _stream()), "mv_paged_decode")
     return out
 
 
 # ---------------------------------------------------------------- K2
 def prefill_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, scale: float,
-                   k_cache=None, v_cache=None, block_tables=None, out=None):
+                   k_cache=None, v_cache=None, block_tables=None, out=None, flags: int | None = None):
     """Packed causal prefill.  Contiguous K/V (k,v [Tk,Hkv,D]) unless ``block_tables`` is
     given, in which case keys come from the paged caches (prefix-cache hit)."""
     _need_cuda(q, cu_seqlens_q, cu_seqlens_k)
@@ -324,7 +354,7 @@ def prefill_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen
     _check(_lib.mv_prefill_varlen(q.data_ptr(), q.stride(0), *args_kv, out.data_ptr(),
                                   _i32(cu_seqlens_q).data_ptr(), _i32(cu_seqlens_k).data_ptr(), n_seqs,
                                   int(max_seqlen_q), int(max_seqlen_k), h, hkv, d, bs, float(scale),
-                                  _dt(q), _stream()), "mv_prefill_varlen")
+                                  _dt(q), PREFILL_FLAGS if flags is None else flags, _stream()), "mv_prefill_varlen")
     return out
 
 
@@ -377,7 +407,12 @@ def linear_small_m_ok(x, weight) -> bool:
             and (x.dim() != 2 or x.stride(0) % 8 == 0))
 
 
-def linear_small_m(x, weight, bias=None):
+def small_m_shape(rpw: int = 0, waves: int = 0, xlds: int = 0, wlds: int = 0) -> int:
+    """Launch-shape override of the small-M kernels (tools/bench_linear.py --sweep): xlds / wlds 1 = on, -1 = off."""
+    return (rpw & 15) | ((waves & 31) << 4) | (({0: 0, 1: 1, -1: 2}[xlds]) << 9) | (({0: 0, 1: 1, -1: 2}[wlds]) << 11)
+
+
+def linear_small_m(x, weight, bias=None, shape: int = 0):
     """x [..., K] (<= 64 rows), weight [N, K], bias [N] | None -> [..., N]; fp32 accumulation."""
     _need_cuda(x, weight)
     x2, k = _rows2d(x)
@@ -388,11 +423,11 @@ def linear_small_m(x, weight, bias=None):
         raise ValueError("bias dtype/shape mismatch")
     out = torch.empty((x2.shape[0], n), dtype=x.dtype, device=x.device)
     _check(_lib.mv_linear_small_m(x2.data_ptr(), x2.stride(0), weight.data_ptr(), _ptr(bias), out.data_ptr(),
-                                  out.stride(0), x2.shape[0], n, k, _dt(x), _stream()), "mv_linear_small_m")
+                                  out.stride(0), x2.shape[0], n, k, _dt(x), int(shape), _stream()), "mv_linear_small_m")
     return out.view(*x.shape[:-1], n)
 
 
-def gate_up_silu_small_m(x, weight):
+def gate_up_silu_small_m(x, weight, shape: int = 0):
     """x [..., K] (<= 64 rows), weight [2I, K] = [gate rows ; up rows] -> silu(x Wg^T) * (x Wu^T), [..., I]."""
     _need_cuda(x, weight)
     x2, k = _rows2d(x)
@@ -401,7 +436,7 @@ def gate_up_silu_small_m(x, weight):
     n = weight.shape[0] // 2
     out = torch.empty((x2.shape[0], n), dtype=x.dtype, device=x.device)
     _check(_lib.mv_gate_up_silu_small_m(x2.data_ptr(), x2.stride(0), weight.data_ptr(), out.data_ptr(),
-                                        out.stride(0), x2.shape[0], n, k, _dt(x), _stream()),
+                                        out.stride(0), x2.shape[0], n, k, _dt(x), int(shape), _stream()),
            "mv_gate_up_silu_small_m")
     return out.view(*x.shape[:-1], n)
 

@@ -9,9 +9,6 @@ import argparse
 import os
 import sys
 
-if "--sweep" in sys.argv:
-    os.environ["MV_LINEAR_TUNE"] = "1"   # before libmvhip.so is loaded: lets the launch-shape overrides through
-
 import torch
 import torch.nn.functional as F
 
@@ -53,7 +50,9 @@ def main():
     ap.add_argument("--models", default="qwen3-1.7b,qwen2-7b")
     ap.add_argument("--ms", default="1,8,16,32,64")
     ap.add_argument("--only", default="")
-    ap.add_argument("--sweep", action="store_true", help="sweep MV_LINEAR_RPW x MV_LINEAR_WAVES per shape")
+    ap.add_argument("--xlds", type=int, default=0, help="1 / -1: force x through LDS on / off")
+    ap.add_argument("--wlds", type=int, default=0, help="1 / -1: force W through LDS on / off")
+    ap.add_argument("--sweep", action="store_true", help="sweep row tiles per wave x waves per shape (explicit launch-shape argument)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     torch.manual_seed(0)
@@ -82,12 +81,12 @@ def main():
                         for waves in (2, 4, 8, 16):
                             if waves * rpw * ((m + 15) // 16) > 64:
                                 continue
-                            os.environ["MV_LINEAR_RPW"], os.environ["MV_LINEAR_WAVES"] = str(rpw), str(waves)
-                            res.append((timed(lambda i: hip_ops.linear_small_m(x, ws[i % copies], bias), ncall), rpw, waves))
-                    del os.environ["MV_LINEAR_RPW"], os.environ["MV_LINEAR_WAVES"]
+                            shape = hip_ops.small_m_shape(rpw, waves)
+                            res.append((timed(lambda i: hip_ops.linear_small_m(x, ws[i % copies], bias, shape), ncall), rpw, waves))
                     res.sort()
                     print(f"   sweep {name} M={m}: " + "  ".join(f"r{r}w{w}={t:.1f}" for t, r, w in res[:6]), flush=True)
-                t_mv = timed(lambda i: hip_ops.linear_small_m(x, ws[i % copies], bias), ncall)
+                forced = hip_ops.small_m_shape(0, 0, a.xlds, a.wlds)
+                t_mv = timed(lambda i: hip_ops.linear_small_m(x, ws[i % copies], bias, forced), ncall)
                 print(f"{model:11s} {name:8s} {m:3d} {n:7d} {k:6d} {wbytes/1e6:7.1f} | {t_lib:8.2f} {wbytes/t_lib/1e6:6.2f} | "
                       f"{t_mv:8.2f} {wbytes/t_mv/1e6:6.2f} | {t_lib/t_mv:5.2f} {err:.3g} (lib {err_lib:.3g})", flush=True)
             del ws
