@@ -257,8 +257,16 @@ int mv_ar_ipc_handle_bytes(void);
 int mv_ar_ipc_export(void *base, void *handle_out);
 int mv_ar_ipc_open(const void *handle, void **ptr_out);
 int mv_ar_ipc_close(void *ptr);
-/* 0 while every peer wait so far was satisfied (a wait that gave up sets it; results are then invalid) */
+/* Status block of the own region, 8 words: [0] number of peer waits that gave up so far (0 = every result is
+ * valid)  [1] != 0 once the record below is filled  [2] phase | peer << 8 | block << 16 | kernel << 24 of the
+ * FIRST expired wait (kernel 0 = mv_ar_all_reduce, 1 = the fused row kernel)  [3] the epoch (call number) it
+ * waited for  [4] the flag value it last saw (an older epoch: the peer never reached this call)  [5] the wait
+ * bound in ms (mv_ar_set_wait_limit_ms; default 20 000).  mv_ar_status synchronises the device;
+ * mv_ar_status_async copies the block on `stream` into PINNED host memory (read it after that stream work is
+ * known complete, e.g. together with a decode step's tokens). */
 int mv_ar_status(void *base, size_t max_bytes, uint32_t *status_out);
+int mv_ar_status_async(void *base, size_t max_bytes, uint32_t *pinned_host_out, void *stream);
+int mv_ar_set_wait_limit_ms(void *base, size_t max_bytes, uint32_t ms);
 int mv_ar_all_reduce(const void *x, void *out, int64_t n, void *const *bases,
                      int rank, int world, size_t max_bytes, int dtype, void *stream);
 
@@ -268,7 +276,7 @@ int mv_ar_all_reduce(const void *x, void *out, int64_t n, void *const *bases,
  *   out      <- ((s * rsqrt(mean(s^2)+eps)) * norm_w) -> dtype,  s the unrounded fp32 sum above
  * = dist.all_reduce (minivllm/models/layers/linear.py:316-318) + RMSNorm.add_rms_forward
  * (layers/layernorm.py:95-105), rounding points of the unfused pair.  norm_w == NULL: out <- the plain
- * row-wise all-reduce, residual untouched.  m % world == 0, k % 8 == 0, k <= 4096, m*k*2 <= max_bytes. */
+ * row-wise all-reduce, residual untouched.  m % world == 0, k % 8 == 0, k <= 8192, m*k*2 <= max_bytes. */
 int mv_ar_all_reduce_add_rmsnorm(const void *x, void *residual, const void *norm_w,
                                  float eps, void *out, int m, int k,
                                  void *const *bases, int rank, int world,

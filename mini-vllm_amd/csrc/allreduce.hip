@@ -18,8 +18,13 @@
 // Cross-GPU visibility does not rely on cache state: the region is allocated uncached
 // (hipDeviceMallocUncached), peer data is read with system-scope (sc0 sc1) loads, flags are
 // system-scope atomics, and a system-scope fence separates data from flag on both sides.
-// Every wait is BOUNDED: a peer that never arrives makes the kernel give up, set status != 0 and finish
-// (the host checks status after its validation run and falls back to RCCL) — the grid always drains.
+// Every wait is BOUNDED in wall-clock time (s_memrealtime, 100 MHz): a peer that never arrives makes the kernel
+// give up, count the expired wait in the status block and finish — the grid always drains.  The FIRST expired
+// wait also leaves a record (which barrier phase, which peer, which block, the epoch it waited for and the flag
+// value it last saw), so a time-out explains itself: a flag that still holds an OLD epoch means the peer never
+// reached this call (not launched, dead, or descheduled for longer than the bound); a flag AHEAD of the epoch
+// cannot expire.  The host reads the block after its validation run (falls back to RCCL) and, while serving,
+// with every step's token copy (raises: a rank that continued with incomplete sums must not keep serving).
 #include <string.h>
 
 #include "common.h"
@@ -29,7 +34,11 @@ namespace {
 constexpr int kMaxWorld = 8;
 constexpr int kArBlocks = 32;       // workgroups per launch (= flag slots per rank and phase)
 constexpr int kArThreads = 512;
-constexpr int kSpinLimit = 20000000;  // bounded wait: tens of seconds of polling, then give up
+constexpr uint32_t kDefaultWaitMs = 20000;   // bounded wait per barrier (wall clock); mv_ar_set_wait_limit_ms changes it
+// status block (uint32 words at status_off): [0] expired waits so far  [1] first-record claimed
+// [2] phase | peer << 8 | block << 16 | kernel << 24  [3] epoch waited for  [4] flag value last seen
+// [5] wait limit in ms (host-written)
+enum { kStExpired = 0, kStClaim = 1, kStWhere = 2, kStEpoch = 3, kStSeen = 4, kStLimitMs = 5, kStWords = 8 };
 
 struct ArRegion {
   // byte offsets inside a rank's region
@@ -74,7 +83,7 @@ __device__ __forceinline__ uint32_t *flag_ptr(char *base, const ArRegion &L, int
 
 // Block-level barrier with the same block of every peer.  Thread q < world handles peer q.
 __device__ __forceinline__ void peer_barrier(const ArParams &p, const ArRegion &L, int parity, int phase,
-                                             uint32_t epoch, uint32_t *status) {
+                                             uint32_t epoch, uint32_t *status, int kernel_id = 0) {
   __threadfence_system();  // this thread's staging stores are performed before the flag goes out
   __syncthreads();
   const int q = threadIdx.x;
@@ -84,11 +93,18 @@ __device__ __forceinline__ void peer_barrier(const ArParams &p, const ArRegion &
                          __HIP_MEMORY_SCOPE_SYSTEM);
     if (q != p.rank) {
       uint32_t *mine = flag_ptr(p.base[p.rank], L, parity, phase, q, blockIdx.x);
-      int spins = 0;
+      const uint64_t t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, constant
+      const uint64_t limit = (uint64_t)__hip_atomic_load(status + kStLimitMs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 100000ull;
+      uint32_t seen;
       // epochs only grow; a flag from a later call (>= epoch + 2, same parity) also means "arrived"
-      while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-        if (++spins > kSpinLimit) {
-          __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      while ((int32_t)((seen = __hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) - epoch) < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > limit) {
+          __hip_atomic_fetch_add(status + kStExpired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (__hip_atomic_exchange(status + kStClaim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+            status[kStWhere] = (uint32_t)phase | ((uint32_t)q << 8) | ((uint32_t)blockIdx.x << 16) | ((uint32_t)kernel_id << 24);
+            status[kStEpoch] = epoch;
+            status[kStSeen] = seen;
+          }
           break;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -178,8 +194,9 @@ __global__ void __launch_bounds__(kArThreads) allreduce_two_shot_kernel(ArParams
 // i.e. dist.all_reduce followed by RMSNorm.add_rms_forward (minivllm/models/layers/linear.py:316-318,
 // layers/layernorm.py:95-105) with the rounding points of the unfused pair (the sum is rounded to dtype
 // before the residual is added).  norm_w == nullptr: plain row-wise all-reduce into out.
-constexpr int kRowVecMax = 8;  // 16-byte vectors per lane and row: K <= 4096 (template NV = 4 or 8; a whole row of
-                               // K = 8192 per wave would spill: such models keep the unfused pair)
+constexpr int kRowVecMax = 16; // 16-byte vectors per lane and row: K <= 8192 (template NV = 4, 8 or 16; at NV = 16 —
+                               // Qwen2-72B's hidden size — a wave holds 2 x 64 packed registers of one row, inside
+                               // the 256 a 512-thread workgroup's waves may use)
 
 struct ArRowParams {
   ArParams ar;        // x = [M][K] partial sums (row stride K), out = normed output (or the plain sum)
@@ -210,7 +227,7 @@ __global__ void __launch_bounds__(kArThreads) allreduce_rows_kernel(ArRowParams 
   // 0. copy-in
   for (int r = blockIdx.x + NB * wave; r < rp.M; r += NB * nw)
     for (int v = lane; v < nv; v += 64) mine[(int64_t)r * nv + v] = xin[(int64_t)r * nv + v];
-  peer_barrier(p, L, parity, 0, epoch, status);
+  peer_barrier(p, L, parity, 0, epoch, status, 1);
 
   // 2. reduce the rows of slice `rank`
   for (int r = blockIdx.x + NB * wave; r < rp.M; r += NB * nw) {
@@ -235,7 +252,7 @@ __global__ void __launch_bounds__(kArThreads) allreduce_rows_kernel(ArRowParams 
       mine[(int64_t)r * nv + v] = pack8<Tag>(acc);
     }
   }
-  peer_barrier(p, L, parity, 1, epoch, status);
+  peer_barrier(p, L, parity, 1, epoch, status, 1);
 
   // 4. gather (+ residual add + RMSNorm): one row per wave at a time, the row stays in registers
   u32x4 *out = (u32x4 *)p.out;
@@ -249,7 +266,7 @@ __global__ void __launch_bounds__(kArThreads) allreduce_rows_kernel(ArRowParams 
       const int v = lane + 64 * i;
       if (v < nv) {
         a[i] = load_sys(make_rsrc(p.base[owner] + stage_off, L.staging_bytes), (uint32_t)(((int64_t)r * nv + v) * 16));
-        if (nwp) b[i] = res[(int64_t)r * nv + v];
+        if (NV <= 8 && nwp) b[i] = res[(int64_t)r * nv + v];
       }
     }
     if (!nwp) {
@@ -259,6 +276,41 @@ __global__ void __launch_bounds__(kArThreads) allreduce_rows_kernel(ArRowParams 
       continue;
     }
     float ss = 0.f;
+    if constexpr (NV > 8) {
+      // wide rows (K = 8192): only the reduced row stays in registers (64 packed); the residual is read twice
+      // from this GPU's own L2 instead — once for the row norm, once to form the sum that is stored and scaled
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < nv) {
+          float fa[8], fb[8];
+          unpack8<Tag>(a[i], fa);
+          unpack8<Tag>(res[(int64_t)r * nv + lane + 64 * i], fb);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            fa[e] = __fadd_rn(fa[e], fb[e]);
+            ss = fmaf(fa[e], fa[e], ss);
+          }
+        }
+      ss = wave_sum(ss);
+      const float rs = 1.0f / sqrtf(ss / (float)rp.K + rp.eps);
+      asm volatile("" ::: "memory");   // the second residual read and the weight read start here, not above
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < nv) {
+          float fa[8], fb[8], fw[8], y[8];
+          unpack8<Tag>(a[i], fa);
+          unpack8<Tag>(res[(int64_t)r * nv + lane + 64 * i], fb);
+          unpack8<Tag>(nwp[lane + 64 * i], fw);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            fa[e] = __fadd_rn(fa[e], fb[e]);
+            y[e] = __fmul_rn(__fmul_rn(fa[e], rs), fw[e]);
+          }
+          res[(int64_t)r * nv + lane + 64 * i] = pack8<Tag>(fa);  // residual <- (sum + residual) -> dtype
+          out[(int64_t)r * nv + lane + 64 * i] = pack8<Tag>(y);
+        }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i)
       if (lane + 64 * i < nv) {
@@ -375,7 +427,8 @@ extern "C" int mv_ar_all_reduce_add_rmsnorm(const void *x, void *residual, const
 #define MV_AR_ROWS(TAG)                                                                                   \
   do {                                                                                                    \
     if (nvl <= 4) hipLaunchKernelGGL((allreduce_rows_kernel<TAG, 4>), grid, block, 0, st, rp);          \
-    else hipLaunchKernelGGL((allreduce_rows_kernel<TAG, 8>), grid, block, 0, st, rp);                   \
+    else if (nvl <= 8) hipLaunchKernelGGL((allreduce_rows_kernel<TAG, 8>), grid, block, 0, st, rp);     \
+    else hipLaunchKernelGGL((allreduce_rows_kernel<TAG, 16>), grid, block, 0, st, rp);                  \
   } while (0)
   if (dtype == MV_BF16) MV_AR_ROWS(bf16_tag);
   else MV_AR_ROWS(f16_tag);
@@ -434,10 +487,24 @@ extern "C" int mv_ar_alloc(size_t max_bytes, void **base_out) {
   if (e != hipSuccess) return (int)e;
   e = hipMemset(p, 0, total);
   if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
+  const uint32_t limit = kDefaultWaitMs;
+  e = hipMemcpy((char *)p + ar_layout(max_bytes).status_off + kStLimitMs * sizeof(uint32_t), &limit, sizeof(limit),
+                hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
   e = hipDeviceSynchronize();
   if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
   *base_out = p;
   return MV_OK;
+}
+
+// how long a barrier of this rank's launches waits for a peer before giving up (default 20 s)
+extern "C" int mv_ar_set_wait_limit_ms(void *base, size_t max_bytes, uint32_t ms) {
+  if (!base) return MV_E_NULLPTR;
+  if (ms == 0) return MV_E_RANGE;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return (int)e;
+  return mv_check_hip(hipMemcpy((char *)base + ar_layout(max_bytes).status_off + kStLimitMs * sizeof(uint32_t), &ms,
+                                sizeof(ms), hipMemcpyHostToDevice));
 }
 
 extern "C" int mv_ar_free(void *base) { return base ? mv_check_hip(hipFree(base)) : MV_OK; }
@@ -458,13 +525,22 @@ extern "C" int mv_ar_ipc_open(const void *handle, void **ptr_out) {
 
 extern "C" int mv_ar_ipc_close(void *ptr) { return ptr ? mv_check_hip(hipIpcCloseMemHandle(ptr)) : MV_OK; }
 
-// status word of the own region: 0 = every wait so far was satisfied.  Host call, synchronises the device.
+// status block of the own region (8 words, see kSt*): word 0 = 0 while every wait so far was satisfied.
+// Host call, synchronises the device.
 extern "C" int mv_ar_status(void *base, size_t max_bytes, uint32_t *status_out) {
   if (!base || !status_out) return MV_E_NULLPTR;
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return (int)e;
-  return mv_check_hip(hipMemcpy(status_out, (char *)base + ar_layout(max_bytes).status_off, sizeof(uint32_t),
+  return mv_check_hip(hipMemcpy(status_out, (char *)base + ar_layout(max_bytes).status_off, kStWords * sizeof(uint32_t),
                                 hipMemcpyDeviceToHost));
+}
+
+// the same 8 words copied asynchronously on `stream` into pinned host memory: rides along with a decode step's
+// token copy, so the host sees a time-out with the step it happened in, without an extra synchronisation
+extern "C" int mv_ar_status_async(void *base, size_t max_bytes, uint32_t *pinned_host_out, void *stream) {
+  if (!base || !pinned_host_out) return MV_E_NULLPTR;
+  return mv_check_hip(hipMemcpyAsync(pinned_host_out, (char *)base + ar_layout(max_bytes).status_off,
+                                     kStWords * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
 }
 
 extern "C" int mv_ar_all_reduce(const void *x, void *out, int64_t n, void *const *bases, int rank, int world,

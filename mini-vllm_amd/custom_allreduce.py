@@ -6,7 +6,13 @@ Set-up is collective and conservative: every rank allocates one uncached region,
 exchanged through the process group, and the kernel is then VALIDATED against the backend's own
 all-reduce on exact (integer-valued) data, several calls back to back.  Only if every rank reports
 success is the kernel used; any failure (allocation, IPC, a wait that gave up, a mismatch) leaves RCCL
-in charge.  ``MV_CUSTOM_AR=0`` disables it."""
+in charge.  ``MV_CUSTOM_AR=0`` disables it.
+
+While serving, a peer wait that gives up (a stalled or dead rank) must not go unnoticed: the kernel then
+finishes with incomplete sums, and ranks that sample different tokens fall out of the lock-step SPMD schedule.
+The status block of the region therefore travels to the host with every step's token copy
+(``post_status`` / ``verify``); a non-zero count raises ``PeerWaitExpired`` with the record of the first
+expired wait (phase, peer, block, epoch waited for, flag value seen)."""
 from __future__ import annotations
 
 import ctypes
@@ -20,7 +26,26 @@ from . import hip_ops
 
 logger = logging.getLogger(__name__)
 
-__all__ = ["CustomAllReduce", "maybe_create"]
+__all__ = ["CustomAllReduce", "PeerWaitExpired", "maybe_create", "describe_status"]
+
+
+class PeerWaitExpired(RuntimeError):
+    """A bounded wait of the peer-to-peer all-reduce gave up: this rank's sums are incomplete."""
+
+
+def describe_status(words) -> str:
+    """Human-readable form of the 8-word status block (csrc/allreduce.hip: kSt*)."""
+    w = [int(x) & 0xFFFFFFFF for x in words]
+    if w[0] == 0:
+        return "ok"
+    where = w[2]
+    kernel = {0: "all_reduce", 1: "all_reduce_add_rmsnorm"}.get(where >> 24, str(where >> 24))
+    seen, want = w[4], w[3]
+    lag = (want - seen) & 0xFFFFFFFF
+    return (f"{w[0]} peer wait(s) expired after {w[5]} ms; first: kernel {kernel}, barrier phase {where & 255} "
+            f"('{'inputs staged' if (where & 255) == 0 else 'slice reduced'}'), waiting for rank {(where >> 8) & 255}, "
+            f"block {(where >> 16) & 255}, call #{want}; the peer's flag still held #{seen} "
+            f"({lag} call(s) behind: the peer never reached this call)")
 
 MAX_BYTES = 8 << 20           # largest message taken (256 tokens x 8192 x 2 B = 4 MiB for Qwen2-72B)
 _lib = hip_ops._lib
@@ -44,6 +69,8 @@ class CustomAllReduce:
         self.bases = (ctypes.c_void_p * 8)()
         self.ready = False
         self.calls = 0
+        self._status_ring = None   # pinned [slots, 8] uint32 (as int64-safe int32 bits) for post_status / verify
+        self._status_slot = 0
 
     # ------------------------------------------------------------------ collective set-up
     def setup(self) -> bool:
@@ -120,13 +147,14 @@ class CustomAllReduce:
                     ok = torch.equal(got, want) and torch.equal(inplace, want)
                     if not ok and good:
                         logger.warning("custom all-reduce validation: mismatch on rank %d (%s, n=%d, call %d, "
-                                       "%d / %d elements differ, status %d)", self.rank, dtype, n, i,
-                                       int((got != want).sum()), int((inplace != want).sum()), self.status())
+                                       "%d / %d elements differ; %s)", self.rank, dtype, n, i,
+                                       int((got != want).sum()), int((inplace != want).sum()),
+                                       describe_status(self.status_words()))
                     good = good and ok
         # the fused all-reduce + add + RMSNorm launch against the unfused pair (exact sums -> identical inputs
         # to the norm; the row norm itself may differ in the last bit of rstd: compare within 2 ulp)
         for dtype, (m, k) in ((torch.bfloat16, (8 * self.world, 2048)), (torch.float16, (self.world, 3584)),
-                              (torch.bfloat16, (256, 2048))):
+                              (torch.bfloat16, (256, 2048)), (torch.bfloat16, (256, 8192)), (torch.float16, (64, 8192))):
             if m % self.world:
                 m += self.world - m % self.world
             for _ in range(3):
@@ -142,13 +170,13 @@ class CustomAllReduce:
                       and bool(((got.float() - want.float()).abs() <= 2 * eps * want.float().abs() + 1e-6).all()))
                 if not ok and good:
                     logger.warning("custom all-reduce validation: fused add+RMSNorm mismatch on rank %d (%s, %dx%d, "
-                                   "residual equal: %s, status %d)", self.rank, dtype, m, k,
-                                   torch.equal(got_res, want_res), self.status())
+                                   "residual equal: %s; %s)", self.rank, dtype, m, k,
+                                   torch.equal(got_res, want_res), describe_status(self.status_words()))
                 good = good and ok
-        st = self.status()
-        if st != 0:
-            logger.warning("custom all-reduce validation: a peer wait timed out on rank %d", self.rank)
-        return good and st == 0
+        words = self.status_words()
+        if words[0] != 0:
+            logger.warning("custom all-reduce validation on rank %d: %s", self.rank, describe_status(words))
+        return good and words[0] == 0
 
     # ------------------------------------------------------------------ use
     def accepts(self, x: torch.Tensor) -> bool:
@@ -171,7 +199,7 @@ class CustomAllReduce:
     def accepts_rows(self, x: torch.Tensor) -> bool:
         """[M, K] activations the fused all-reduce + add + RMSNorm launch takes."""
         return (self.accepts(x) and x.dim() == 2 and x.shape[0] % self.world == 0 and x.shape[1] % 8 == 0
-                and x.shape[1] <= 4096)
+                and x.shape[1] <= 8192)
 
     def all_reduce_add_rmsnorm(self, x, residual, norm_weight, eps: float):
         """-> (normed, residual): ``x`` summed over the ranks, added to ``residual`` (updated in place),
@@ -185,11 +213,39 @@ class CustomAllReduce:
         self.calls += 1
         return out, residual
 
+    def status_words(self) -> list[int]:
+        """The 8-word status block (host call: synchronises the device); word 0 = expired waits so far."""
+        st = (ctypes.c_uint32 * 8)()
+        hip_ops._check(_lib.mv_ar_status(self.base, self.max_bytes, st), "mv_ar_status")
+        return [int(v) for v in st]
+
     def status(self) -> int:
         """0 while every peer wait of every call so far was satisfied (host call: synchronises the device)."""
-        st = ctypes.c_uint32(0)
-        hip_ops._check(_lib.mv_ar_status(self.base, self.max_bytes, ctypes.byref(st)), "mv_ar_status")
-        return int(st.value)
+        return self.status_words()[0]
+
+    def set_wait_limit_ms(self, ms: int) -> None:
+        hip_ops._check(_lib.mv_ar_set_wait_limit_ms(self.base, self.max_bytes, int(ms)), "mv_ar_set_wait_limit_ms")
+
+    # -- per-step check without an extra synchronisation --------------------------------------------------
+    def post_status(self) -> int:
+        """Enqueue an async copy of the status block on the current stream into a pinned ring slot; returns the
+        slot.  Call right after the step's work was enqueued (next to the token copy)."""
+        if self._status_ring is None:
+            self._status_ring = torch.zeros((8, 8), dtype=torch.int32, pin_memory=True)
+        slot = self._status_slot
+        self._status_slot = (slot + 1) % self._status_ring.shape[0]
+        hip_ops._check(_lib.mv_ar_status_async(self.base, self.max_bytes, self._status_ring[slot].data_ptr(),
+                                               hip_ops._stream()), "mv_ar_status_async")
+        return slot
+
+    def verify(self, slot: int) -> None:
+        """After the stream work up to ``post_status`` is known complete (the step's tokens were read): raise if
+        any peer wait has expired — this rank's activations are then sums over a subset of the ranks."""
+        words = self._status_ring[slot].tolist()
+        if words[0] != 0:
+            self.ready = False
+            raise PeerWaitExpired(f"tensor-parallel all-reduce on rank {self.rank}: {describe_status(words)}; "
+                                  "the results of this step are invalid, stopping")
 
     def close(self) -> None:
         self.ready = False

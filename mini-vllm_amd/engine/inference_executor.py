@@ -21,7 +21,8 @@ import torch
 
 from ..config import Config
 from ..layers.sampler import Sampler
-from ..parallel_state import get_tensor_parallel_world_size, decode_step_is_native, tp_greedy_tokens
+from ..parallel_state import (decode_step_is_native, get_custom_all_reduce as get_custom_allreduce,
+                              get_tensor_parallel_world_size, tp_greedy_tokens)
 from ..utils.context import reset_context, set_context
 from .. import hip_ops
 from .input_builder import BatchInputs, InputBuilder
@@ -94,6 +95,7 @@ class InferenceExecutor:
         self.allow_speculation = os.environ.get("MV_DECODE_SPECULATE", "1") != "0"
         self._spec = None            # (batch, bucket, expected lens, event, host token slot) of the step in flight
         self._tok_host = [torch.zeros(ms, dtype=torch.int64, pin_memory=self.device.type == "cuda") for _ in range(3)]
+        self._ar_slots: list = [None] * 3   # custom all-reduce status slot posted with each token copy
         self._tok_events = [torch.cuda.Event() for _ in range(3)] if self.device.type == "cuda" else []
         self._tok_slot = 0
         self.spec_hits = self.spec_misses = 0
@@ -194,6 +196,7 @@ class InferenceExecutor:
         if not sequences:
             return torch.empty(0, device=self.device), []
         try:
+            eager = True
             if prefill:
                 self._drop_speculation()  # a speculative decode step in flight (if any) is simply ignored
                 inp = self.builder.prefill(sequences)
@@ -206,17 +209,32 @@ class InferenceExecutor:
                 inp = self.builder.decode(sequences, pad_to=bs)
                 if bs is not None and inp.packed:
                     logits, tokens = self._replay_graph(bs, inp, sequences)
+                    eager = False
                 else:
                     self._drop_speculation()
                     ids, pos = self._ship_decode(inp)
                     greedy = self._tp_greedy(sequences)
                     logits = self.model.compute_logits(self.model(ids, pos), gather=not greedy)
                     tokens = self._sample_tokens(logits, sequences, tp_greedy=greedy)
+            self._check_peer_waits(eager)
             self._update_metrics(sequences, prefill)
             self.inference_count += 1
             return logits, tokens
         finally:
             reset_context()
+
+    def _check_peer_waits(self, eager: bool) -> None:
+        """Tensor parallel on the peer-to-peer all-reduce: a wait that gave up (stalled / dead rank) left this rank
+        with sums over a subset of the ranks.  The kernel's status block came back with this step's tokens
+        (graph path: _stash_tokens / _replay_graph); eager steps read it here, after their tokens were read (the
+        stream is idle then).  Raises custom_allreduce.PeerWaitExpired: the engine must not keep serving."""
+        ar = get_custom_allreduce() if self.tp_size > 1 else None
+        if ar is None or not ar.ready:
+            return
+        if eager:
+            slot = ar.post_status()
+            torch.cuda.current_stream().synchronize()
+            ar.verify(slot)
 
     def _to_dev(self, t: torch.Tensor | None):
         return None if t is None else t.to(self.device, non_blocking=True)
@@ -483,6 +501,8 @@ class InferenceExecutor:
             graph.replay()
             self._spec = (list(sequences), bs, [s.num_tokens + 1 for s in sequences], self._stash_tokens(b), graph)
         self._tok_events[slot_now].synchronize()
+        if self._ar_slots[slot_now] is not None:     # the all-reduce status block that travelled with these tokens
+            get_custom_allreduce().verify(self._ar_slots[slot_now])
         return (gv["logits_local"] if greedy else gv["logits"])[:b], self._tok_host[slot_now][:b].tolist()
 
     def _drop_speculation(self) -> None:
@@ -497,6 +517,8 @@ class InferenceExecutor:
         slot = self._tok_slot
         self._tok_slot = (slot + 1) % len(self._tok_host)
         self._tok_host[slot][:b].copy_(self.graph_vars["tokens"][:b], non_blocking=True)
+        ar = get_custom_allreduce() if self.tp_size > 1 else None
+        self._ar_slots[slot] = ar.post_status() if ar is not None and ar.ready else None
         self._tok_events[slot].record()
         return slot
 

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "mv_ar_ipc_open": (c_int, [c_void_p, c_void_p]),
     "mv_ar_ipc_close": (c_int, [c_void_p]),
     "mv_ar_status": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "mv_ar_status_async": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mv_ar_set_wait_limit_ms": (c_int, [c_void_p, c_size_t, ctypes.c_uint32]),
     "mv_ar_all_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_size_t, c_int, c_void_p]),
     "mv_ar_all_reduce_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p,
                                              c_int, c_int, c_size_t, c_int, c_void_p]),

@@ -206,6 +206,70 @@ def test_tp2_logits_match_reference_on_one_gpu(golden_dir, tmp_path):
         assert r["greedy_ok"], r
 
 
+# ---------------------------------------------------------------------------------- config 5 shapes, world 8 (CPU)
+def _config5_worker(rank, world, port, out_path):
+    """BASELINE config 5: Qwen2-72B-Instruct, TP = 8.  Head split 64/8 -> 8/1 per rank, vocab 152064/8,
+    intermediate 29568/8; Qwen2-7B (28/4 heads) is rejected at TP = 8 exactly like the reference
+    (minivllm/models/qwen_base.py:95-104).  True dimensions on the meta device (shapes only), then the same head
+    counts at a small head_dim with real numbers: every rank's shard is the slice the reference's loaders cut."""
+    _init(rank, world, port)
+    import torch.nn.functional as F
+
+    from minivllm_amd.engine.inference_executor import kv_block_bytes
+    from minivllm_amd.glue.qwen import QwenAttention, QwenMLP
+    from minivllm_amd.layers.embed_head import ParallelLMHead, VocabParallelEmbedding
+    from minivllm_amd.layers.linear import QKVParallelLinear, RowParallelLinear
+
+    errs = []
+    with torch.device("meta"):
+        attn = QwenAttention(hidden_size=8192, num_heads=64, num_kv_heads=8, max_position=4096, qkv_bias=True)
+        mlp = QwenMLP(8192, 29568, "silu")
+        emb, head = VocabParallelEmbedding(152064, 8192), ParallelLMHead(152064, 8192)
+    errs.append((attn.num_heads, attn.num_kv_heads, attn.head_dim, attn.q_size, attn.kv_size) == (8, 1, 128, 1024, 128))
+    errs.append(tuple(attn.qkv_proj.weight.shape) == ((8 + 2 * 1) * 128, 8192) and tuple(attn.qkv_proj.bias.shape) == (1280,))
+    errs.append(tuple(attn.o_proj.weight.shape) == (8192, 1024))
+    errs.append(tuple(mlp.gate_up_proj.weight.shape) == (2 * 3696, 8192) and tuple(mlp.down_proj.weight.shape) == (8192, 3696))
+    errs.append(tuple(emb.weight.shape) == (19008, 8192) and emb.vocab_start_idx == rank * 19008 and tuple(head.weight.shape) == (19008, 8192))
+    # per-GPU KV block: 2 (K,V) x 80 layers x 64 tokens x 1 LOCAL kv head x 128 x 2 B = 2.5 MiB (SURVEY §8 a10)
+    errs.append(kv_block_bytes(80, 64, attn.num_kv_heads, 128, 2) == 2621440)
+    try:   # Qwen2-7B: 28 q heads / 4 kv heads do not divide by 8
+        with torch.device("meta"):
+            QwenAttention(hidden_size=3584, num_heads=28, num_kv_heads=4, max_position=4096, qkv_bias=True)
+        errs.append(False)
+    except ValueError as e:
+        errs.append("divisible" in str(e))
+    # the same 64/8 head split with numbers: head_dim 4, hidden 64
+    g = torch.Generator().manual_seed(5)
+    hd, H, Hkv, hidden = 4, 64, 8, 64
+    wq, wk, wv = (torch.randn(n * hd, hidden, generator=g) for n in (H, Hkv, Hkv))
+    wo = torch.randn(hidden, H * hd, generator=g)
+    qkv, o = QKVParallelLinear(hidden, hd, H, Hkv), RowParallelLinear(H * hd, hidden)
+    for w, sid in ((wq, "q"), (wk, "k"), (wv, "v")):
+        qkv.weight.weight_loader(qkv.weight, w, sid)
+    o.weight.weight_loader(o.weight, wo)
+    x = torch.randn(3, hidden, generator=g)
+    y = qkv(x)
+    qs, ks = H * hd // world, Hkv * hd // world     # 8 q heads, 1 kv head per rank
+    errs.append(torch.equal(y[:, :qs], F.linear(x, wq[rank * qs:(rank + 1) * qs]))
+                and torch.equal(y[:, qs:qs + ks], F.linear(x, wk[rank * ks:(rank + 1) * ks]))
+                and torch.equal(y[:, qs + ks:], F.linear(x, wv[rank * ks:(rank + 1) * ks])))
+    # q heads of rank r attend kv head r (groups stay together): o_proj over the rank's q slice, summed over ranks
+    q_full = F.linear(x, wq)
+    want = F.linear(q_full, wo)
+    got = o(q_full[:, rank * qs:(rank + 1) * qs].contiguous())
+    errs.append(bool(torch.allclose(got, want, rtol=1e-4, atol=1e-4)))
+    dist.barrier()
+    open(out_path + f".{rank}", "w").write("ok" if all(errs) else f"bad {errs}")
+    dist.destroy_process_group()
+
+
+def test_config5_qwen2_72b_tp8_shapes_cpu_gloo(tmp_path):
+    out = str(tmp_path / "res")
+    mp.spawn(_config5_worker, args=(8, _free_port(), out), nprocs=8, join=True)
+    for rank in range(8):
+        assert open(out + f".{rank}").read() == "ok", rank
+
+
 # ---------------------------------------------------------------------------------- GPU, peer-to-peer all-reduce
 def _custom_ar_worker(rank, world, port, out_path):
     _init(rank, world, port)
@@ -213,9 +277,9 @@ def _custom_ar_worker(rank, world, port, out_path):
     from minivllm_amd import parallel_state
     from minivllm_amd.custom_allreduce import maybe_create
 
-    # set-up includes the exact validation against gloo; its verdict is collective, so a retry (a box busy
-    # enough to exhaust a bounded wait) is taken by every rank together
-    ar = maybe_create(rank, world, torch.device("cuda", 0)) or maybe_create(rank, world, torch.device("cuda", 0))
+    # set-up includes the exact validation against gloo.  ONE attempt: a failure is logged with the status
+    # record of the first expired wait (custom_allreduce.describe_status) and fails the test
+    ar = maybe_create(rank, world, torch.device("cuda", 0))
     ok = ar is not None
     errs = []
     if ok:
@@ -235,8 +299,9 @@ def _custom_ar_worker(rank, world, port, out_path):
         # bits; the row norm may differ in the last bit of rstd)
         from minivllm_amd import hip_ops
 
+        # ... including Qwen2-72B's hidden size (config 5: m = 256 rows x k = 8192 per GPU at TP = 8)
         for (m, k), dtype in (((4 * world, 2048), torch.bfloat16), ((world, 3584), torch.float16),
-                              ((256, 1024), torch.bfloat16)):
+                              ((256, 1024), torch.bfloat16), ((256, 8192), torch.bfloat16), ((16, 8192), torch.float16)):
             x = torch.randn((m, k), generator=g).to(dtype).cuda()
             res = torch.randn((m, k), generator=g).to(dtype).cuda()
             w = (1 + 0.1 * torch.randn(k, generator=g)).to(dtype).cuda()
@@ -262,6 +327,43 @@ def _custom_ar_worker(rank, world, port, out_path):
     open(out_path + f".{rank}", "w").write("ok" if ok else f"bad {errs}")
     parallel_state.reset_tensor_parallel()
     dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_a_peer_that_never_arrives_is_reported_not_ignored():
+    """One rank launches its all-reduce and its peer never does (here: a second region in the SAME process plays
+    the mapped peer region and nobody ever writes its flags).  The bounded wait gives up, the kernel drains, and
+    the status block that travels with the step says which wait expired; ``verify`` raises."""
+    import ctypes
+
+    from minivllm_amd import hip_ops
+    from minivllm_amd.custom_allreduce import CustomAllReduce, PeerWaitExpired, describe_status
+
+    dev = torch.device("cuda", 0)
+    ar = CustomAllReduce(0, 2, dev, max_bytes=1 << 20)
+    lib = hip_ops.lib()
+    peer = ctypes.c_void_p()
+    try:
+        hip_ops._check(lib.mv_ar_alloc(ar.max_bytes, ctypes.byref(ar.base)), "mv_ar_alloc")
+        hip_ops._check(lib.mv_ar_alloc(ar.max_bytes, ctypes.byref(peer)), "mv_ar_alloc")
+        ar.bases[0], ar.bases[1] = ar.base.value, peer.value
+        ar.set_wait_limit_ms(50)
+        ar.ready = True
+        assert ar.status_words()[0] == 0 and ar.status_words()[5] == 50
+        x = torch.ones(4096, dtype=torch.bfloat16, device=dev)
+        ar.all_reduce(x)                       # rank 1 never shows up
+        slot = ar.post_status()
+        torch.cuda.synchronize()               # returns: every wait is bounded, the grid drains
+        with pytest.raises(PeerWaitExpired, match="waiting for rank 1"):
+            ar.verify(slot)
+        words = ar.status_words()
+        assert words[0] >= 1 and words[3] == 1 and words[4] == 0, describe_status(words)   # call #1, flag still 0
+        assert "never reached this call" in describe_status(words)
+        assert not ar.ready
+    finally:
+        if peer:
+            lib.mv_ar_free(peer)
+        ar.close()
 
 
 @pytest.mark.gpu
