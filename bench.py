@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="enforce_eager (no hipGraph)")
     ap.add_argument("--synthetic-kv", action="store_true",
                     help="fill the KV cache with random values instead of running the prompt prefill")
+    ap.add_argument("--auto-kv", action="store_true",
+                    help="size the KV pool from free HBM (num_kvcache_blocks=-1, the way a user runs it) instead of "
+                         "allocating exactly what this workload needs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -83,7 +86,8 @@ def build_engine(args, workdir):
     cfg = Config(workdir, dtype="bfloat16", kvcache_block_size=64, max_num_seqs=args.batch,
                  max_model_len=max_len, max_num_batched_tokens=max(16384, max_len),
                  tensor_parallel_size=args.gpus, enforce_eager=args.eager, load_format="dummy", seed=0,
-                 num_kvcache_blocks=args.batch * (-(-(args.ctx + args.steps + args.warmup + 8) // 64) + 1))
+                 num_kvcache_blocks=-1 if args.auto_kv else
+                 args.batch * (-(-(args.ctx + args.steps + args.warmup + 8) // 64) + 1))
     return LLM(cfg)
 
 
@@ -208,8 +212,12 @@ def cpu_baseline(args):
         if (steps >= 2 and el > args.cpu_seconds) or steps >= 64:
             break
     return {"value": round(b * steps / el, 2), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{args.model} fp32 (the reference's CPU dtype, examples/cpu_inference_opt.py:143-151) random weights, decode only, B={b}, ctx {ctx}->{ctx + steps}, "
-                      f"{steps} steps in {el:.1f}s on {os.cpu_count()} logical CPUs (oracle/model.py; build {build_s:.0f}s)"}
+            "sample": f"{args.model} fp32 (the reference's CPU dtype, examples/cpu_inference_opt.py:143-151) random weights, "
+                      f"decode only, B={b}, ctx {ctx}->{ctx + steps}, {steps} steps in {el:.1f}s (oracle/model.py; build "
+                      f"{build_s:.0f}s).  A bounded sample of the headline model, NOT the headline batch: the CPU path "
+                      f"needs minutes per step at B={args.batch}, ctx {args.ctx}; tokens/s per sequence at B={b} is the "
+                      f"CPU's best case (weights are re-read per step whatever B is).  cores = torch's intra-op threads "
+                      f"(its default, one per physical core) of {os.cpu_count()} logical CPUs (2 hardware threads per core)"}
 
 
 def main():
@@ -249,14 +257,21 @@ def main():
         roof = decode_roofline(engine, args)
         ex = engine.model_runner.inference_executor
         graphs = bool(ex.graphs or ex.greedy_graphs)
-        allreduce = None
+        allreduce = tp_info = None
         if args.gpus > 1:
             from minivllm_amd import parallel_state
+            from minivllm_amd.custom_allreduce import describe_status
 
             ar = parallel_state.get_custom_all_reduce()
+            words = ar.status_words() if ar is not None else None
             allreduce = "rccl" if ar is None else (
                 f"p2p two-shot kernel (validated against the backend at start-up, {ar.calls} calls)"
-                if ar.status() == 0 else "p2p two-shot kernel: A PEER WAIT TIMED OUT, RESULT INVALID")
+                if words[0] == 0 else f"p2p two-shot kernel: RESULT INVALID, {describe_status(words)}")
+            # what the process group actually is: backend "nccl" = RCCL on ROCm, and how many ranks it spans
+            tp_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                       "activation_all_reduce": "rccl" if ar is None else "p2p",
+                       "all_reduces_per_step": 2 * MODELS[args.model]["num_hidden_layers"] + 1,
+                       "logit_exchange": "per-rank argmax merge (greedy batch): no [B, V/tp] all-gather"}
         kv_blocks = engine.config.num_kvcache_blocks
         engine.exit()
     if rank != 0:
@@ -270,7 +285,8 @@ def main():
         "config": {"workload": f"{args.model} decode, B={args.batch}, ctx={args.ctx}, kvcache_block_size=64, "
                                f"max_num_seqs={args.batch}, {'hipGraph' if graphs else 'eager'} decode, greedy",
                    "model": args.model, "global_batch": args.batch, "seq_len": args.ctx,
-                   "parallelism": f"tp{args.gpus}", "allreduce": allreduce, "kv_blocks": kv_blocks,
+                   "parallelism": f"tp{args.gpus}", "allreduce": allreduce, "tensor_parallel": tp_info,
+                   "kv_blocks": kv_blocks, "kv_sizing": "from free HBM (auto)" if args.auto_kv else "explicit",
                    "prefill": "synthetic KV" if args.synthetic_kv else "engine prefill"},
         "prefill_tokens_per_s": None if prefill_tps is None else round(prefill_tps, 1),
         "roofline": roof, "cpu_baseline": cpu,

@@ -307,71 +307,6 @@ def test_speculative_replay_matches_eager_across_finishes(golden_dir, tmp_path):
     assert stats[0] == (0, 0) and stats[1][0] > 5                          # eager never speculates; graphs did
 
 
-def test_config2_qwen3_0p6b_true_dims_vs_cpu_oracle(tmp_path):
-    """BASELINE config 2: Qwen3-0.6B dimensions (28 layers, 16/8 heads, D=128, vocab 151936), bf16,
-    enforce_eager — GPU logits against the CPU oracle (fp32 math on the same bf16 weights), prefill and
-    three decode steps.  Weights are random (no checkpoint offline) but shared bit for bit."""
-    import bench
-    from oracle.model import OracleModel
-
-    from minivllm_amd.config import Config
-    from minivllm_amd.engine.block_manager import BlockManager
-    from minivllm_amd.engine.inference_executor import InferenceExecutor
-    from minivllm_amd.engine.input_builder import InputBuilder
-    from minivllm_amd.engine.sequence import Sequence
-    from minivllm_amd.glue import create_model
-
-    cfg_d = dict(bench.MODELS["qwen3-0.6b"])
-    cfg_d["num_hidden_layers"] = 8          # true width / heads / vocab; 8 of the 28 layers keep the CPU side short
-    (tmp_path / "config.json").write_text(json.dumps(cfg_d))
-    ref = OracleModel.random(cfg_d, dtype=torch.bfloat16, seed=1, num_blocks=8)
-    for k in list(ref.w):                   # sharpen the norms a little so that they matter
-        if k.endswith("norm.weight"):
-            ref.w[k] = (1 + 0.1 * torch.randn(ref.w[k].shape, generator=torch.Generator().manual_seed(len(k)))).bfloat16()
-    cfg = Config(str(tmp_path), num_kvcache_blocks=8, max_model_len=512, max_num_batched_tokens=1024, max_num_seqs=4,
-                 enforce_eager=True, dtype="bfloat16")
-    prev = torch.get_default_dtype()
-    torch.set_default_dtype(torch.bfloat16)
-    try:
-        with torch.device(DEV):
-            model = create_model(cfg.hf_config)
-    finally:
-        torch.set_default_dtype(prev)
-    model.load_weights({k: v.float() for k, v in ref.w.items()})
-    model = model.to(device=DEV, dtype=torch.bfloat16)
-    ex = InferenceExecutor(cfg, model, torch.device(DEV))
-    ex._allocate_kv_cache(); ex._initialize_sampler(); ex._optimize_model()
-    # fp32 oracle on the same (bf16-representable) weights
-    ref32 = OracleModel(cfg_d, {k: v.float() for k, v in ref.w.items()}, torch.float32, num_blocks=8)
-    g = torch.Generator().manual_seed(0)
-    prompts = [torch.randint(0, cfg_d["vocab_size"], (n,), generator=g).tolist() for n in (70, 33)]
-    bm, ib = BlockManager(8, 64), InputBuilder(64, 4, 512, 1024)
-    seqs = [Sequence(p, block_size=64) for p in prompts]
-    for s in seqs:
-        bm.allocate(s)
-
-    def oracle_step(prefill):
-        inp = ib.prefill(seqs) if prefill else ib.decode(seqs)
-        meta = dict(is_prefill=prefill, slot_mapping=inp.slot_mapping, block_tables=inp.block_tables,
-                    cu_q=inp.cum_seqlens_q, cu_k=inp.cum_seqlens_k, context_lens=inp.context_lens)
-        return ref32.forward_logits(inp.input_ids.clone(), inp.positions.clone(), meta).float()
-
-    for step in range(4):
-        want = oracle_step(step == 0)
-        got, toks = ex.execute_batch(seqs, prefill=(step == 0))
-        got = got.float().cpu()
-        scale = want.abs().max().item()
-        err = (got - want).abs().max().item()
-        # bf16 activations through 8 layers against fp32 math: a few bf16 ulps of the logit scale
-        assert err <= 0.03 * scale, f"step {step}: err {err:.4f} scale {scale:.3f}"
-        cos = torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item()
-        assert cos > 0.999, f"step {step}: cosine {cos}"   # the reference's own model-level bar is 0.99
-        nxt = want.argmax(-1).tolist()
-        for s, t in zip(seqs, nxt):
-            s.append_token(int(t))
-            bm.may_append(s)
-
-
 def test_kv_cache_auto_sizing_and_graph_buckets(golden_dir, tmp_path):
     """a10: with num_kvcache_blocks=-1 the pool is min(memory budget // block bytes, max_num_seqs *
     ceil(max_model_len / block)) and is written back into the Config (the scheduler sizes itself from it)."""
@@ -392,6 +327,60 @@ def test_kv_cache_auto_sizing_and_graph_buckets(golden_dir, tmp_path):
     assert graph_batch_sizes(8) == [1, 2, 4, 8] and graph_batch_sizes(1000)[-1] == 512
     assert graph_batch_sizes(24) == [1, 2, 4, 8, 12, 16, 24] and graph_batch_sizes(3) == [1, 2, 3]
     assert graph_batch_sizes(1) == [1]
+
+
+def test_kv_pool_sized_by_hbm_not_by_the_cap(tmp_path):
+    """a10 on the real part: num_kvcache_blocks=-1 with limits so large (max_num_seqs 512 x max_model_len 40960 =
+    327 680 blocks = 2.2 TiB of Qwen3-1.7B KV) that the 288 GB of HBM, not the cap, decide.  The pool must fit the
+    budget util * total - used, be allocated, serve a request, and be addressable to its LAST block (7 MiB blocks:
+    byte offsets beyond 2^37).  Formula: minivllm/engine/inference_executor.py:245-318 with the local kv heads."""
+    import gc
+
+    import bench
+    from oracle import ops as O
+
+    from minivllm_amd import LLM, Config, SamplingParams, hip_ops
+    from minivllm_amd.engine.inference_executor import kv_block_bytes
+
+    (tmp_path / "config.json").write_text(json.dumps(bench.MODELS["qwen3-1.7b"]))
+    free0, total = torch.cuda.mem_get_info()
+    cfg = Config(str(tmp_path), dtype="bfloat16", kvcache_block_size=64, max_num_seqs=512, max_model_len=40960,
+                 max_num_batched_tokens=40960, enforce_eager=True, load_format="dummy", seed=0, num_kvcache_blocks=-1)
+    engine = LLM(cfg)
+    try:
+        ex = engine.model_runner.inference_executor
+        n = cfg.num_kvcache_blocks
+        bb = kv_block_bytes(28, 64, 8, 128, 2)
+        assert bb == 7 << 20
+        assert 0 < n < 512 * (40960 // 64), "the cap decided: this GPU is not memory-limited for the test's limits"
+        assert ex.kv_cache.shape == (2, 28, n, 64, 8, 128)
+        used_before_kv = total - free0 + 0   # other processes + this context before the engine existed
+        assert n * bb <= cfg.device_memory_utilization * total - used_before_kv
+        # not wasteful either: what is left of the budget after weights + pool is less than 4 GiB of slack
+        free1, _ = torch.cuda.mem_get_info()
+        budget_left = cfg.device_memory_utilization * total - (total - free1)
+        print(f"\nKV pool on this GPU: {n} blocks x 7 MiB = {n * bb / 2**30:.1f} GiB of {total / 2**30:.1f} GiB "
+              f"(util {cfg.device_memory_utilization}); budget left {budget_left / 2**30:.2f} GiB")
+        assert -1 * 2**30 <= budget_left <= 4 * 2**30, budget_left
+        # the engine serves with it
+        outs = engine.generate([[5, 6, 7, 8, 9], list(range(100, 170))], SamplingParams(temperature=0.0, max_tokens=5,
+                                                                                         ignore_eos=True), use_tqdm=False)
+        assert [len(o["token_ids"]) for o in outs] == [5, 5]
+        # the last block of the last layer is real memory at the right address: write it, read it through the kernel
+        kc, vc = ex.kv_cache[0, 27], ex.kv_cache[1, 27]
+        kc[n - 1].normal_(); vc[n - 1].normal_(); kc[0].normal_(); vc[0].normal_()
+        q = torch.randn(2, 16, 128, device=DEV).bfloat16()
+        table = torch.tensor([[n - 1, 0], [0, n - 1]], dtype=torch.int32, device=DEV)
+        ctx = torch.tensor([64, 100], dtype=torch.int32, device=DEV)
+        out = hip_ops.paged_decode(q, kc, vc, table, ctx, 128 ** -0.5)
+        small_k, small_v = torch.stack([kc[0], kc[n - 1]]).cpu(), torch.stack([vc[0], vc[n - 1]]).cpu()
+        ref = O.paged_decode(q.cpu(), small_k, small_v, torch.tensor([[1, 0], [0, 1]], dtype=torch.int32), ctx.cpu(), 128 ** -0.5)
+        torch.testing.assert_close(out.float().cpu(), ref, rtol=2 ** -7, atol=2 ** -7)
+    finally:
+        engine.exit()
+        del engine
+        gc.collect()
+        torch.cuda.empty_cache()
 
 
 def test_randomized_serving_speculation_changes_nothing(golden_dir, tmp_path, monkeypatch):
@@ -456,4 +445,7 @@ def test_randomized_serving_speculation_changes_nothing(golden_dir, tmp_path, mo
     eager, _ = serve(eager=True, speculate=False)
     agree = sum(a == b for a, b in zip(eager, plain))
     print(f"eager vs graph: {agree} of {len(reqs)} requests identical")
-    assert agree >= 24
+    # measured: 40 of 40.  Eager steps run unpadded batches, graph steps the next bucket: a different split-KV plan
+    # can move a logit by an ulp, and a sampled row sitting on a probability edge then draws another token and
+    # diverges for good — a slack of 2 requests for that, no more (a real regression loses most of them)
+    assert agree >= len(reqs) - 2

@@ -105,3 +105,39 @@ def test_sampler_filters_match_reference(G):
     assert torch.equal(keep_m, t(G["samp_keep_minp"]))
     keep, _ = O.sampler_keep_mask(logits, temps, top_ks, top_ps, min_ps)
     assert torch.equal(keep, t(G["samp_keep_minp"]))
+
+
+# ---------------------------------------------------------------- SURVEY §8(c) wide cases (tests/golden/ops_wide.npz)
+@pytest.fixture(scope="module")
+def GW(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_wide.npz"))
+
+
+def _wide_cases(kind):
+    import golden_inputs as GI
+
+    return [c["name"] for c in (GI.WIDE_DECODE if kind == "decode" else GI.WIDE_PREFILL)]
+
+
+@pytest.mark.parametrize("name", _wide_cases("decode"))
+def test_paged_decode_wide_matches_reference(GW, name):
+    """Head layouts 16/8, 28/4, 8/1, 12/12 and contexts 1..4096: inputs regenerated from their seed (checksum
+    pinned in the fixture), output against what the reference's PageAttention produced."""
+    import golden_inputs as GI
+
+    case = next(c for c in GI.WIDE_DECODE if c["name"] == name)
+    q, kc, vc, table, ctx = GI.wide_decode_inputs(case)
+    assert GI.checksum(q, kc, vc, table, ctx) == float(GW[f"decode_{name}_checksum"]), "seeded inputs drifted"
+    out = O.paged_decode(q.float(), kc.float(), vc.float(), table, ctx, case["D"] ** -0.5)
+    torch.testing.assert_close(out, t(GW[f"decode_{name}_out"]), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", _wide_cases("prefill"))
+def test_prefill_wide_matches_reference(GW, name):
+    import golden_inputs as GI
+
+    case = next(c for c in GI.WIDE_PREFILL if c["name"] == name)
+    q, k, v, cu = GI.wide_prefill_inputs(case)
+    assert GI.checksum(q, k, v, cu) == float(GW[f"prefill_{name}_checksum"]), "seeded inputs drifted"
+    out = O.prefill_varlen(q.float(), k.float(), v.float(), cu, cu, case["D"] ** -0.5)
+    torch.testing.assert_close(out[GI.wide_prefill_rows(case)], t(GW[f"prefill_{name}_out_rows"]), rtol=1e-4, atol=2e-5)

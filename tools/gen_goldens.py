@@ -8,6 +8,7 @@ nothing under /root/reference is modified and nothing from it is copied into the
 the fixtures are data only: seeded inputs and the outputs the reference produced.
 
     python tools/gen_goldens.py            # rewrites tests/golden/*.npz / *.json
+    python tools/gen_goldens.py wide config2   # only the SURVEY §8(c) wide cases / the true-dimension config 2 run
 """
 from __future__ import annotations
 
@@ -446,12 +447,117 @@ def e2e(tmp):
         print(f"e2e_{name}.npz: {len(z)} arrays")
 
 
+# ----------------------------------------------------------------------------- the wide cases
+def wide_goldens():
+    """Decode at the head layouts 16/8, 28/4, 8/1, 12/12 with contexts up to 4096, and prefill up to 1024 tokens per
+    sequence (the same outputs pin the prefix-cached prefill: its rows are the new-token rows of the full no-cache
+    prefill).  Inputs are regenerated from their seeds on the test side (tests/golden_inputs.py); stored: the
+    reference's fp32 outputs and a checksum of the inputs it saw."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_inputs as GI
+
+    z = {}
+    for case in GI.WIDE_DECODE:
+        q, kc, vc, table, ctx = GI.wide_decode_inputs(case)
+        scale = case["D"] ** -0.5
+        out = PageAttention()(q.float(), kc.float(), vc.float(), table, ctx, scale)
+        z[f"decode_{case['name']}_out"] = f32(out)
+        z[f"decode_{case['name']}_checksum"] = np.float64(GI.checksum(q, kc, vc, table, ctx))
+    for case in GI.WIDE_PREFILL:
+        q, k, v, cu = GI.wide_prefill_inputs(case)
+        attn = Attention(case["H"], case["D"], case["D"] ** -0.5, case["Hkv"])
+        set_context(True, max(case["lens"]), max(case["lens"]), cu, cu, None, None, None)
+        out = attn(q.float(), k.float(), v.float())
+        reset_context()
+        z[f"prefill_{case['name']}_out_rows"] = f32(out.reshape(q.shape)[GI.wide_prefill_rows(case)])
+        z[f"prefill_{case['name']}_checksum"] = np.float64(GI.checksum(q, k, v, cu))
+    np.savez_compressed(os.path.join(OUT, "ops_wide.npz"), **z)
+    print(f"ops_wide.npz: {len(z)} arrays")
+
+
+def config2_golden(tmp):
+    """BASELINE config 2 at its true dimensions: Qwen3-0.6B, all 28 layers, seeded bf16-representable weights
+    (tests/golden_inputs.py::seeded_hf_weights), prefill of two prompts + 3 teacher-forced decode steps through the
+    reference's InferenceExecutor in fp32 and in bf16.  Stored per step: the fp32 logits at 512 fixed vocabulary
+    columns and their top-8, the logit scale, and the reference's OWN bf16-vs-fp32 error (the noise floor the
+    bf16 parity bound is taken from)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_inputs as GI
+
+    d = os.path.join(tmp, "config2")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(GI.CONFIG2, f)
+    hfw = GI.seeded_hf_weights(GI.CONFIG2)
+    prompts, cols = GI.config2_prompts(), GI.config2_columns()
+    z = {"weights_checksum": np.float64(GI.checksum(hfw["model.embed_tokens.weight"][:64],
+                                                    hfw["model.layers.27.mlp.down_proj.weight"][:8],
+                                                    hfw["model.layers.0.self_attn.q_norm.weight"])),
+         "columns": cols.numpy()}
+    full = {}
+    for tag, dt in (("f32", "float32"), ("bf16", "bfloat16")):
+        cfg = Config(d, num_kvcache_blocks=8, kvcache_block_size=64, max_model_len=512, max_num_batched_tokens=1024,
+                     max_num_seqs=4, enforce_eager=True, dtype=dt)
+        model = create_model(cfg.hf_config)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if name.endswith("qkv_proj.weight"):
+                    b = name[: -len("qkv_proj.weight")]
+                    src = torch.cat([hfw[b + "q_proj.weight"], hfw[b + "k_proj.weight"], hfw[b + "v_proj.weight"]])
+                elif name.endswith("gate_up_proj.weight"):
+                    b = name[: -len("gate_up_proj.weight")]
+                    src = torch.cat([hfw[b + "gate_proj.weight"], hfw[b + "up_proj.weight"]])
+                elif name == "lm_head.weight":
+                    src = hfw["model.embed_tokens.weight"]
+                else:
+                    src = hfw[name]
+                p.copy_(src.float())
+        model = model.to(getattr(torch, dt))
+        ex = InferenceExecutor(cfg, model)
+        ex._allocate_kv_cache(); ex._initialize_sampler(); ex._optimize_model()
+        bm = BlockManager(8, 64)
+        seqs = [Sequence(p, SamplingParams(temperature=1.0, max_tokens=64, ignore_eos=True), block_size=64) for p in prompts]
+        for s in seqs:
+            bm.allocate(s)
+        forced = []
+        for step in range(GI.CONFIG2_DECODE_STEPS + 1):
+            with torch.inference_mode():
+                logits, _ = ex.execute_batch(seqs, prefill=(step == 0))
+            logits = logits.float()
+            if tag == "f32":
+                full[step] = logits.clone()
+                top = logits.topk(8, dim=-1)
+                z[f"cols_{step}"] = f32(logits[:, cols])
+                z[f"top_idx_{step}"] = top.indices.numpy().astype(np.int64)
+                z[f"top_val_{step}"] = f32(top.values)
+                z[f"scale_{step}"] = np.float32(logits.abs().max())
+                toks = logits.argmax(-1).tolist()
+                forced.append(toks)
+            else:
+                z[f"ref_bf16_noise_{step}"] = np.float32((logits - full[step]).abs().max())
+                toks = z["forced_tokens"][step].tolist()
+            for s, t in zip(seqs, toks):
+                s.append_token(int(t))
+                bm.may_append(s)
+        if tag == "f32":
+            z["forced_tokens"] = np.array(forced, dtype=np.int64)
+        del model, ex
+    np.savez_compressed(os.path.join(OUT, "e2e_config2_qwen3_0p6b.npz"), **z)
+    print("e2e_config2_qwen3_0p6b.npz:", {k: (float(v) if v.ndim == 0 else v.shape) for k, v in z.items() if "noise" in k or "scale" in k})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]
     with tempfile.TemporaryDirectory() as tmp:
-        host_traces(tmp)
-        op_goldens()
-        e2e(tmp)
+        if not only or "base" in only:
+            host_traces(tmp)
+            op_goldens()
+            e2e(tmp)
+        if not only or "wide" in only:
+            wide_goldens()
+        if not only or "config2" in only:
+            config2_golden(tmp)
 
 
 if __name__ == "__main__":
