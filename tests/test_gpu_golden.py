@@ -194,6 +194,7 @@ def test_config2_qwen3_0p6b_full_depth_against_the_reference(golden_dir, tmp_pat
     from minivllm_amd.engine.inference_executor import InferenceExecutor
     from minivllm_amd.engine.sequence import Sequence
     from minivllm_amd.glue import create_model
+    from minivllm_amd.sampling_params import SamplingParams
 
     z = np.load(os.path.join(golden_dir, "e2e_config2_qwen3_0p6b.npz"))
     hfw = GI.seeded_hf_weights(GI.CONFIG2)
@@ -214,7 +215,8 @@ def test_config2_qwen3_0p6b_full_depth_against_the_reference(golden_dir, tmp_pat
     ex = InferenceExecutor(cfg, model, torch.device(DEV))
     ex._allocate_kv_cache(); ex._initialize_sampler(); ex._optimize_model()
     bm = BlockManager(8, 64)
-    seqs = [Sequence(p, block_size=64) for p in GI.config2_prompts()]
+    greedy = SamplingParams(temperature=0.0, max_tokens=64, ignore_eos=True)
+    seqs = [Sequence(p, greedy, block_size=64) for p in GI.config2_prompts()]
     for s in seqs:
         bm.allocate(s)
     cols = torch.from_numpy(z["columns"])
