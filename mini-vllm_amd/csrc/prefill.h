@@ -16,4 +16,5 @@ struct PrefillParams {
 // generic vector-ALU path (every dtype, D in {64,128})
 int mv_prefill_simple_launch(const PrefillParams &p, int64_t max_total_q, int dtype, hipStream_t stream);
 // MFMA flash path (bf16/f16, D in {64,128}); returns MV_E_SHAPE when it does not apply
-int mv_prefill_mfma_launch(const PrefillParams &p, int dtype, hipStream_t stream);
+// variant: bench switches (flags >> 4 of mv_prefill_varlen), 0 = the shipped kernel
+int mv_prefill_mfma_launch(const PrefillParams &p, int dtype, int variant, hipStream_t stream);

@@ -41,7 +41,7 @@ extern "C" int mv_prefill_varlen(const void *q, int64_t q_stride_tok, const void
   hipStream_t st = (hipStream_t)stream;
   // MV_PREFILL_SIMPLE routes 16-bit tensors through the vector-ALU kernel (debug aid)
   if (dtype != MV_F32 && !(flags & MV_PREFILL_SIMPLE)) {
-    const int rc = mv_prefill_mfma_launch(p, dtype, st);
+    const int rc = mv_prefill_mfma_launch(p, dtype, flags >> 4, st);
     if (rc != MV_E_SHAPE) return rc;
   }
   return mv_prefill_simple_launch(p, (int64_t)n_seqs * max_seqlen_q, dtype, st);

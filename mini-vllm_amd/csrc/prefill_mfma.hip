@@ -22,7 +22,6 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-constexpr int BM = 128;  // query rows per workgroup
 constexpr int BN = 64;   // keys per tile
 constexpr int D = 128;
 constexpr int NS = D / 16;      // k-steps of the QK^T product
@@ -56,8 +55,17 @@ __device__ __forceinline__ int v_off(int row, int ch) {
   return row * ROW_BYTES + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
 }
 
-template <typename Tag>
-__global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
+// Round 2 (profiles/r02_prefill_kernel.md): the softmax arithmetic is scalar f32 (v_fma_f32 / v_exp_f32 / v_add_f32;
+// the packed v_pk_* forms cost more issue cycles beside MFMAs than the two ops they replace, and this file is built
+// with -fno-slp-vectorize so that the compiler does not pair them either), and a full tile's DMA source addresses
+// are one scalar base + per-lane constants instead of ~90 integer VALU instructions per tile and wave:
+// 743 -> 850 TFLOP/s on 4 x 4096 tokens, 28/4 heads.
+// NW = waves per workgroup (32 query rows each): 4 (two workgroups per CU) or 8 (one; the K/V tile and its DMA
+// instructions — ~100 issue cycles apiece — are shared by twice the rows)
+template <typename Tag, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams p) {
+  constexpr int BM = NW * 32;   // query rows per workgroup
+  constexpr int PP = 16 / NW;   // 1-KiB DMA pieces (4 rows) of a K tile per wave, and as many of the V tile
   typedef typename elem<Tag>::T T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // two K|V tile buffers: tile t+1 is written while tile t is being read -> ONE barrier per tile
@@ -121,8 +129,41 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
   //      linearly per wave (4 rows x 256 B), so both swizzles go on the SOURCE address: lane -> (row, stored
   //      chunk) fetches the logical chunk that belongs there.  Rows past the sequence end re-read the last valid
   //      key (finite data whose probability is exactly 0 after masking); loads are unconditional.
+  // per-lane parts of the DMA source addresses that do not change from tile to tile (non-paged: everything but
+  // the tile's first row; the ragged last tile clamps rows, so it takes the general path below)
+  int64_t krel[PP], vrel[PP];
+#pragma unroll
+  for (int i = 0; i < PP; ++i) {
+    const int row = 4 * (NW * i + wave) + (lane >> 4), pc = lane & 15;
+    krel[i] = (int64_t)row * kstride + (pc ^ (row & 15)) * 8;
+    vrel[i] = (int64_t)row * vstride + (pc ^ (((row & 3) << 2) | ((row >> 2) & 3))) * 8;
+  }
   bool tile_ok_next = true;
   auto dma = [&](int t, int buf) {
+    {
+      const int kv0f = t * BN;
+      if (kv0f + BN <= sk) {   // a full tile: one scalar base + the per-lane constants
+        int64_t base_row = k0 + kv0f;
+        tile_ok_next = true;
+        if (paged) {
+          const int bi = kv0f / p.block_size;
+          const int blk = p.block_tables[(int64_t)seq * p.table_stride + bi];
+          tile_ok_next = blk >= 0 && blk < p.num_blocks;
+          base_row = (int64_t)(tile_ok_next ? blk : 0) * p.block_size + (kv0f - bi * p.block_size);
+        }
+        const T *kt = ksrc + base_row * kstride + hkv * D;
+        const T *vt = vsrc + base_row * vstride + hkv * D;
+        char *dk = smem + buf * 2 * TILE_BYTES, *dv = dk + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PP; ++i) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kt + krel[i]),
+                                           (__attribute__((address_space(3))) void *)(dk + (NW * i + wave) * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vt + vrel[i]),
+                                           (__attribute__((address_space(3))) void *)(dv + (NW * i + wave) * 1024), 16, 0, 0);
+        }
+        return;
+      }
+    }
     const int kv0 = t * BN;
     int64_t base_row = k0 + kv0;
     tile_ok_next = true;
@@ -137,17 +178,17 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
     const int last = sk - 1 - kv0;
     char *dk = smem + buf * 2 * TILE_BYTES, *dv = dk + TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // wave `wave`, instruction i fill LDS rows 4 (4 i + wave) .. +3 linearly: lane -> (row, stored chunk)
+    for (int i = 0; i < PP; ++i) {
+      // wave `wave`, instruction i fill LDS rows 4 (NW i + wave) .. +3 linearly: lane -> (row, stored chunk)
       const int wv = wave;
-      const int row = 4 * (4 * i + wv) + (lane >> 4), pc = lane & 15;
+      const int row = 4 * (NW * i + wv) + (lane >> 4), pc = lane & 15;
       const int srow = min(row, last);
       const int kch = pc ^ (row & 15);
       const int vch = pc ^ (((row & 3) << 2) | ((row >> 2) & 3));
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kt + (int64_t)srow * kstride + kch * 8),
-                                       (__attribute__((address_space(3))) void *)(dk + (4 * i + wv) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void *)(dk + (NW * i + wv) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vt + (int64_t)srow * vstride + vch * 8),
-                                       (__attribute__((address_space(3))) void *)(dv + (4 * i + wv) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void *)(dv + (NW * i + wv) * 1024), 16, 0, 0);
     }
   };
 
@@ -224,20 +265,21 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
     }
-    // two scores per instruction where the ISA has a packed form (v_pk_fma_f32 / v_pk_add_f32)
-    const f32x2 sc2 = {scale_log2, scale_log2}, nm2 = {-m_run, -m_run};
-    f32x2 rs2 = {0.f, 0.f};
+    {
+      // one v_fma_f32 + one v_exp_f32 + one v_add_f32 per score (four independent partial row sums); this file is
+      // built with -fno-slp-vectorize so that the compiler does not pair them into v_pk_* either
+      const float nm = -m_run;
+      float rs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        const f32x2 x = __builtin_elementwise_fma(f32x2{sacc[kt][i], sacc[kt][i + 1]}, sc2, nm2);
-        const f32x2 e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-        sacc[kt][i] = e.x;
-        sacc[kt][i + 1] = e.y;
-        rs2 += e;
-      }
-    l_run += rs2.x + rs2.y;
+        for (int i = 0; i < 16; ++i) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][i], scale_log2, nm));
+          sacc[kt][i] = e;
+          rs[i & 3] += e;
+        }
+      l_run += (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    }
 
     // ---- P^T as MFMA B operand: registers 8*s2 .. 8*s2+7 of a 32-key tile are k-step s2
     u32x4 pf[2][2];
@@ -295,17 +337,26 @@ __global__ void __launch_bounds__(256, 2) prefill_mfma_kernel(PrefillParams p) {
 
 }  // namespace
 
-int mv_prefill_mfma_launch(const PrefillParams &p, int dtype, hipStream_t stream) {
+int mv_prefill_mfma_launch(const PrefillParams &p, int dtype, int variant, hipStream_t stream) {
   if (p.head_dim != D || (dtype != MV_BF16 && dtype != MV_F16)) return MV_E_SHAPE;
   if (p.block_tables && (p.block_size % BN) != 0) return MV_E_SHAPE;  // a 64-key tile must sit in one block
-  const int q_blocks = (p.max_seqlen_q + BM - 1) / BM;
+  // 8 waves (256 query rows) per workgroup share a K/V tile where the sequences are long enough that the larger
+  // blocks still fill the chip evenly; short prompts keep 4 waves x 2 workgroups per CU (measured per shape,
+  // profiles/r02_prefill_kernel.md).  variant (bench switch, flags >> 4): 1 = force 4 waves, 2 = force 8
+  const int nw = variant == 1 ? 4 : (variant == 2 ? 8 : (p.max_seqlen_q >= 2048 ? 8 : 4));
+  const int bm = nw * 32;
+  const int q_blocks = (p.max_seqlen_q + bm - 1) / bm;
   if (q_blocks == 0 || p.n_seqs == 0) return MV_OK;
-  dim3 grid(p.n_heads, p.n_seqs, q_blocks), block(256);
+  dim3 grid(p.n_heads, p.n_seqs, q_blocks), block(nw * 64);
   const size_t lds = 4 * TILE_BYTES;  // 2 x (K tile + V tile) = 64 KiB -> two workgroups per CU
-  if (dtype == MV_BF16)
-    hipLaunchKernelGGL((prefill_mfma_kernel<bf16_tag>), grid, block, lds, stream, p);
-  else
-    hipLaunchKernelGGL((prefill_mfma_kernel<f16_tag>), grid, block, lds, stream, p);
+#define MV_PF_LAUNCH(NWAVES)                                                                   \
+  do {                                                                                        \
+    if (dtype == MV_BF16) hipLaunchKernelGGL((prefill_mfma_kernel<bf16_tag, NWAVES>), grid, block, lds, stream, p); \
+    else hipLaunchKernelGGL((prefill_mfma_kernel<f16_tag, NWAVES>), grid, block, lds, stream, p);                   \
+  } while (0)
+  if (nw == 8) MV_PF_LAUNCH(8);
+  else MV_PF_LAUNCH(4);
+#undef MV_PF_LAUNCH
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

@@ -45,16 +45,16 @@ def bench_decode(B, Hq, Hkv, D, ctx, bs=64, dtype=torch.bfloat16, layers=4):
     return t, bytes_
 
 
-def bench_prefill(n_seqs, seqlen, Hq, Hkv, D=128, dtype=torch.bfloat16):
+def bench_prefill(n_seqs, seqlen, Hq, Hkv, D=128, dtype=torch.bfloat16, variant=0):
     T = n_seqs * seqlen
     q = torch.randn(T, Hq, D, device=DEV).to(dtype)
     k = torch.randn(T, Hkv, D, device=DEV).to(dtype)
     v = torch.randn(T, Hkv, D, device=DEV).to(dtype)
     cu = (torch.arange(n_seqs + 1, device=DEV) * seqlen).to(torch.int32)
     out = torch.empty_like(q)
-    t = timeit(lambda: H.prefill_varlen(q, k, v, cu, cu, seqlen, seqlen, D ** -0.5, out=out), iters=10)
+    t = timeit(lambda: H.prefill_varlen(q, k, v, cu, cu, seqlen, seqlen, D ** -0.5, out=out, flags=variant << 4), iters=10)
     flops = n_seqs * 4 * Hq * D * (seqlen * seqlen - seqlen * (seqlen - 1) / 2)
-    print(f"prefill {n_seqs}x{seqlen} H={Hq}/{Hkv}: {t*1e3:8.3f} ms  {flops/t/1e12:7.1f} TFLOP/s  {T/t/1e6:6.2f} Mtok/s")
+    print(f"prefill {n_seqs}x{seqlen} H={Hq}/{Hkv} variant {variant}: {t*1e3:8.3f} ms  {flops/t/1e12:7.1f} TFLOP/s  {T/t/1e6:6.2f} Mtok/s")
 
 
 def bench_sampler(B, V, temp, top_k, top_p, min_p=0.0, dtype=torch.bfloat16):
@@ -72,13 +72,20 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--prefill-only", action="store_true")
+    ap.add_argument("--variants", default="0", help="prefill kernel bench variants (flags >> 4), comma separated")
     a = ap.parse_args()
     print(torch.cuda.get_device_name(0))
     if a.prefill_only:
-        bench_prefill(16, 1024, 16, 8)
-        bench_prefill(16, 1024, 28, 4)
-        bench_prefill(4, 4096, 28, 4)
-        bench_prefill(64, 256, 28, 4)
+        # the chip's clock ramps over the first second of load: warm up, then interleave the variants and repeat
+        for _ in range(3):
+            bench_prefill(4, 4096, 28, 4)
+        print("--- (warm-up above) ---")
+        for rep in range(3):
+            for var in [int(v) for v in a.variants.split(",")]:
+                bench_prefill(16, 1024, 16, 8, variant=var)
+                bench_prefill(16, 1024, 28, 4, variant=var)
+                bench_prefill(4, 4096, 28, 4, variant=var)
+                bench_prefill(64, 256, 28, 4, variant=var)
         raise SystemExit(0)
     bench_decode(256, 16, 8, 128, 1024)          # Qwen3-1.7B headline
     bench_prefill(16, 1024, 16, 8)               # Qwen3-1.7B, one 16384-token batch
