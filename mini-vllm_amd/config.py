@@ -39,6 +39,9 @@ class Config:
     dtype: str = "auto"
     seed: int | None = None
     load_format: str = "auto"
+    # beyond the reference (opt-in): prompts longer than max_num_batched_tokens are prefilled in chunks
+    # (scheduler.py); max_num_batched_tokens may then be smaller than max_model_len
+    enable_chunked_prefill: bool = False
 
     @property
     def gpu_memory_utilization(self) -> float:
@@ -81,7 +84,7 @@ class Config:
                 raise ValueError(f"{name} must be positive, got {getattr(self, name)}")
         self._load_hf_config()
         self._clamp_max_model_len()
-        if self.max_num_batched_tokens < self.max_model_len:
+        if self.max_num_batched_tokens < self.max_model_len and not self.enable_chunked_prefill:
             raise ValueError(
                 f"max_num_batched_tokens ({self.max_num_batched_tokens}) must be >= max_model_len "
                 f"({self.max_model_len}) to accommodate the full context length in a single batch.")
@@ -114,7 +117,8 @@ class Config:
         if self.hf_config is None:
             return
         model_max = getattr(self.hf_config, "max_position_embeddings", self.DEFAULT_MAX_MODEL_LEN)
-        if self.max_num_batched_tokens < self.max_model_len and model_max < self.max_model_len:
+        if (self.max_num_batched_tokens < self.max_model_len and model_max < self.max_model_len
+                and not self.enable_chunked_prefill):
             new_len = min(model_max, self.max_num_batched_tokens)
             warnings.warn(
                 f"auto-adjusting max_model_len from {self.max_model_len} to {new_len} "

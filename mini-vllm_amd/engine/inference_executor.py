@@ -312,7 +312,7 @@ class InferenceExecutor:
 
     def _update_metrics(self, sequences, prefill: bool) -> None:
         if prefill:
-            self.total_prefill_tokens += sum(len(s) - s.num_cached_tokens for s in sequences)
+            self.total_prefill_tokens += sum(s.prefill_stop - s.num_cached_tokens for s in sequences)
         else:
             self.total_decode_tokens += len(sequences)
         self.total_tokens_generated += len(sequences)

@@ -92,17 +92,19 @@ class InputBuilder:
         cu_q, cu_k = [0], [0]
         max_q = max_k = 0
         for seq in sequences:
-            n, cached = len(seq), seq.num_cached_tokens
-            ids.extend(seq.token_ids[cached:])
+            # n = end of the range this step computes: the whole sequence, or a chunk boundary (a multiple of the
+            # block size) of a prompt that is prefilled in several steps (Sequence.prefill_end)
+            n, cached = seq.prefill_stop, seq.num_cached_tokens
+            ids.extend(seq.token_ids[cached:n])
             pos.append(np.arange(cached, n, dtype=np.int64))
             cu_q.append(cu_q[-1] + n - cached)
             cu_k.append(cu_k[-1] + n)
             max_q, max_k = max(max_q, n - cached), max(max_k, n)
             if seq.block_table:
-                first, last = seq.num_cached_blocks, seq.num_blocks - 1
+                first, last = seq.num_cached_blocks, -(-n // bs) - 1
                 for i in range(first, last + 1):
                     start = seq.block_table[i] * bs
-                    count = bs if i != last else seq.last_block_num_tokens
+                    count = bs if i != last else n - last * bs
                     slots.append(np.arange(start, start + count, dtype=np.int32))
         t = len(ids)
         out_ids = self._fit_i64(0, t)

@@ -122,12 +122,15 @@ class LLMEngine:
             prompt = self.tokenizer.encode(prompt)
         if not prompt:
             raise ValueError("token_ids must contain at least one token")
-        limit = min(self.config.max_num_batched_tokens, self.config.max_model_len)
+        # one prefill step takes max_num_batched_tokens; longer prompts are prefilled in chunks (scheduler.py)
+        limit = self.config.max_model_len
+        if not getattr(self.config, "enable_chunked_prefill", False):
+            limit = min(limit, self.config.max_num_batched_tokens)
         if self.config.num_kvcache_blocks > 0:   # (-1 before the KV cache is sized)
             limit = min(limit, self.config.num_kvcache_blocks * self.config.kvcache_block_size)
         if len(prompt) > limit:
             # beyond the reference, whose scheduler only notices when nothing can be scheduled any more
-            raise ValueError(f"prompt of {len(prompt)} tokens exceeds what one prefill can take (max_num_batched_tokens, max_model_len, KV pool): {limit}")
+            raise ValueError(f"prompt of {len(prompt)} tokens exceeds what can be prefilled (max_model_len, KV pool; max_num_batched_tokens without chunked prefill): {limit}")
         return prompt
 
     def add_request(self, prompt: str | list[int], sampling_params: SamplingParams | None = None) -> int:
@@ -147,9 +150,11 @@ class LLMEngine:
         token_ids = self.model_runner.call("run", sequences, is_prefill)
         if token_ids is None:
             raise RuntimeError("ModelRunner returned no tokens on rank 0")
+        # tokens this step computed (a prefix-cache hit or an earlier chunk is not recomputed), before postprocess
+        # moves the counters
+        num_tokens = sum(s.prefill_stop - s.num_cached_tokens for s in sequences) if is_prefill else -len(sequences)
         self.scheduler.postprocess(sequences, token_ids)
         outputs = [(s.seq_id, s.completion_token_ids) for s in sequences if s.is_finished]
-        num_tokens = sum(len(s) for s in sequences) if is_prefill else -len(sequences)
         return outputs, num_tokens
 
     def is_finished(self) -> bool:

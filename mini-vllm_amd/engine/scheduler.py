@@ -2,7 +2,13 @@
 prefill has priority and packs whole prompts up to max_num_seqs / max_num_batched_tokens;
 otherwise every running sequence decodes one token, preempting the newest when blocks run
 out.  Preempted sequences lose their blocks and are re-prefilled from the front of the queue
-(recompute; the prefix cache often rescues them)."""
+(recompute; the prefix cache often rescues them).
+
+Beyond the reference (BASELINE config 4 "chunked prefill"): a prompt longer than
+max_num_batched_tokens — which the reference can never schedule — is prefilled ALONE in chunks of at most
+max_num_batched_tokens tokens (whole blocks), one chunk per step, each attending the chunks before it through
+the paged KV cache (the prefix-cached form of the prefill kernel).  Only the last chunk's token is kept.  Every
+flow the reference supports schedules exactly as before (the host traces pin that)."""
 from __future__ import annotations
 
 import logging
@@ -26,12 +32,14 @@ class Scheduler:
         # preempt and re-prefill itself for ever)
         self.max_model_len = min(getattr(config, "max_model_len", None) or (1 << 62),
                                  config.num_kvcache_blocks * config.kvcache_block_size)
+        self.chunked_prefill = bool(getattr(config, "enable_chunked_prefill", False))
         self.waiting: deque[Sequence] = deque()
         self.running: deque[Sequence] = deque()
+        self.prefilling: Sequence | None = None   # a long prompt between two of its chunks
         self.num_preemptions = 0
 
     def is_finished(self) -> bool:
-        return not self.waiting and not self.running
+        return not self.waiting and not self.running and self.prefilling is None
 
     def add(self, sequence: Sequence) -> None:
         self.waiting.append(sequence)
@@ -56,9 +64,27 @@ class Scheduler:
             raise RuntimeError(msg)
         return [], False
 
+    def _next_chunk(self, seq: Sequence) -> None:
+        """Set the token range [num_cached_tokens, prefill_end) of the next chunk of a long prompt."""
+        bs = self.block_manager.block_size
+        budget = max(bs, self.max_num_batched_tokens // bs * bs)       # whole blocks
+        end = seq.num_cached_tokens + budget
+        seq.prefill_end = None if end >= len(seq) else end
+
     def _schedule_prefill(self) -> list[Sequence]:
+        if self.prefilling is not None:                                 # the next chunk of the prompt in flight
+            self._next_chunk(self.prefilling)
+            return [self.prefilling]
         batch: list[Sequence] = []
         tokens = 0
+        if (self.chunked_prefill and self.waiting and len(self.waiting[0]) > self.max_num_batched_tokens
+                and self.block_manager.can_allocate(self.waiting[0])):
+            seq = self.waiting.popleft()
+            self.block_manager.allocate(seq)                            # (prefix-cache hits shorten the first chunk)
+            seq.status = SequenceStatus.RUNNING
+            self.prefilling = seq
+            self._next_chunk(seq)
+            return [seq]
         while self.waiting and len(batch) < self.max_num_seqs:
             seq = self.waiting[0]
             # the budget test uses the full length; the charge below only the uncached part
@@ -129,6 +155,13 @@ class Scheduler:
         self.waiting.appendleft(sequence)
 
     def postprocess(self, sequences: list[Sequence], token_ids: list[int]) -> None:
+        if self.prefilling is not None and sequences and sequences[0] is self.prefilling:
+            seq = self.prefilling
+            if seq.prefill_end is not None:          # a middle chunk: its KV is in the cache, its token is not a token
+                seq.num_cached_tokens = seq.prefill_end
+                return
+            self.prefilling = None                   # last chunk: from here on an ordinary running sequence
+            self.running.append(seq)
         for seq, token in zip(sequences, token_ids, strict=True):
             seq.append_token(token)
             hit_eos = token == self.eos and not seq.ignore_eos

@@ -32,6 +32,9 @@ class Sequence:
         self.num_tokens = len(self.token_ids)
         self.num_prompt_tokens = self.num_tokens
         self.num_cached_tokens = 0
+        # chunked prefill (beyond the reference): a prefill step computes tokens
+        # [num_cached_tokens, prefill_end); None = up to the end of the sequence (the reference's only mode)
+        self.prefill_end: int | None = None
         self.block_table: list[int] = []
         self.block_size = block_size
         self._adopt_sampling(sp)
@@ -76,6 +79,11 @@ class Sequence:
     def last_block_num_tokens(self) -> int:
         return self.num_tokens - (self.num_blocks - 1) * self.block_size
 
+    @property
+    def prefill_stop(self) -> int:
+        """End (exclusive) of the token range the next prefill step computes."""
+        return self.num_tokens if self.prefill_end is None else self.prefill_end
+
     def block(self, i: int) -> list[int]:
         if not 0 <= i < self.num_blocks:
             raise IndexError(
@@ -116,5 +124,6 @@ class Sequence:
             self.token_ids = payload
             self.last_token = payload[-1] if payload else 0
         self.status = SequenceStatus.RUNNING if decoding else SequenceStatus.WAITING
+        self.prefill_end = None
         self._adopt_sampling(SamplingParams(temperature=temperature, top_p=top_p, top_k=top_k,
                                             min_p=min_p, max_tokens=max_tokens, ignore_eos=ignore_eos))

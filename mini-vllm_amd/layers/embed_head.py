@@ -29,8 +29,10 @@ class VocabParallelEmbedding(nn.Module):
         self.weight.weight_loader = self.weight_loader
 
     def weight_loader(self, param, loaded_weight, *args, **kwargs):
+        from ..utils.loader import materialize
+
         shard = param.data.size(0)
-        param.data.copy_(loaded_weight.narrow(0, self.tp_rank * shard, shard))
+        param.data.copy_(materialize(loaded_weight.narrow(0, self.tp_rank * shard, shard)))
 
     def extra_repr(self) -> str:
         return (f"num_embeddings={self.num_embeddings}, embedding_dim={self.weight.shape[1]}, "

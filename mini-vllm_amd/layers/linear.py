@@ -22,6 +22,7 @@ from torch import nn
 from .. import hip_ops
 from ..parallel_state import (divide, get_tensor_parallel_rank, get_tensor_parallel_world_size,
                               tp_all_reduce)
+from ..utils.loader import materialize
 
 __all__ = ["LinearBase", "ReplicatedLinear", "ColumnParallelLinear", "MergedColumnParallelLinear",
            "QKVParallelLinear", "RowParallelLinear", "divide", "linear", "small_m", "PartialSum", "mid_plan"]
@@ -176,7 +177,7 @@ class LinearBase(nn.Module):
 
 class ReplicatedLinear(LinearBase):
     def weight_loader(self, param, loaded_weight, *args, **kwargs):
-        param.data.copy_(loaded_weight)
+        param.data.copy_(materialize(loaded_weight))
 
     def forward(self, x):
         return linear(x, self.weight, self.bias, self.weight_packed)
@@ -190,7 +191,7 @@ class ColumnParallelLinear(LinearBase):
 
     def weight_loader(self, param, loaded_weight, *args, **kwargs):
         shard = param.data.size(0)
-        param.data.copy_(loaded_weight.narrow(0, self.tp_rank * shard, shard))
+        param.data.copy_(materialize(loaded_weight.narrow(0, self.tp_rank * shard, shard)))
 
     def forward(self, x):
         return linear(x, self.weight, self.bias, self.weight_packed)
@@ -207,7 +208,7 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
         offset = sum(self.output_sizes[:loaded_shard_id]) // self.tp_size
         size = self.output_sizes[loaded_shard_id] // self.tp_size
         piece = loaded_weight.chunk(self.tp_size, 0)[self.tp_rank]
-        param.data.narrow(0, offset, size).copy_(piece)
+        param.data.narrow(0, offset, size).copy_(materialize(piece))
 
 
 class QKVParallelLinear(ColumnParallelLinear):
@@ -231,7 +232,7 @@ class QKVParallelLinear(ColumnParallelLinear):
         except KeyError:
             raise AssertionError(f"Invalid shard_id: {loaded_shard_id}") from None
         piece = loaded_weight.chunk(self.tp_size, 0)[self.tp_rank]
-        param.data.narrow(0, offset, size).copy_(piece)
+        param.data.narrow(0, offset, size).copy_(materialize(piece))
 
     def extra_repr(self) -> str:
         return (f"hidden_size={self.input_size}, head_size={self.head_size}, num_heads={self.num_heads}, "
@@ -248,10 +249,10 @@ class RowParallelLinear(LinearBase):
     def weight_loader(self, param, loaded_weight, *args, **kwargs):
         if param.data.dim() == 1:
             if self.tp_rank == 0:
-                param.data.copy_(loaded_weight)
+                param.data.copy_(materialize(loaded_weight))
             return
         shard = param.data.size(1)
-        param.data.copy_(loaded_weight.narrow(1, self.tp_rank * shard, shard))
+        param.data.copy_(materialize(loaded_weight.narrow(1, self.tp_rank * shard, shard)))
 
     def forward(self, x, reduce: bool = True, partial_ok: bool = False):
         """``reduce=False`` returns this rank's partial product: the caller sums it together with the

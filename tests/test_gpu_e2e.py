@@ -329,6 +329,43 @@ def test_kv_cache_auto_sizing_and_graph_buckets(golden_dir, tmp_path):
     assert graph_batch_sizes(1) == [1]
 
 
+def test_chunked_prefill_equals_one_shot_prefill(golden_dir, tmp_path):
+    """SURVEY §8 f4 / BASELINE config 4: a 300-token prompt prefilled in chunks of 128 (each chunk attends the
+    earlier ones through the paged cache) must produce the logits of the one-shot prefill, and the same greedy
+    continuation."""
+    from safetensors.torch import save_file
+
+    from minivllm_amd import LLM, Config, SamplingParams
+
+    z = _load(golden_dir, "qwen3")
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    (d / "config.json").write_text(bytes(z["config_json"]).decode())
+    save_file({k[2:]: torch.from_numpy(z[k].view(np.int16).copy()).view(torch.bfloat16).contiguous()
+               for k in z.files if k.startswith("w:")}, str(d / "model.safetensors"))
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(0, 320, (n,), generator=g).tolist() for n in (300, 5, 129)]
+    sp = SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True)
+    outs, logits = [], []
+    for budget, chunked in ((1024, False), (128, True)):
+        cfg = Config(str(d), max_model_len=512, max_num_batched_tokens=budget, max_num_seqs=4, num_kvcache_blocks=24,
+                     enforce_eager=True, dtype="bfloat16", enable_chunked_prefill=chunked)
+        engine = LLM(cfg)
+        ex = engine.model_runner.inference_executor
+        seen = []
+        real = ex.execute_batch
+        ex.execute_batch = lambda seqs, prefill=True, _r=real, _s=seen: (lambda r: (_s.append((prefill, [s.prefill_stop - s.num_cached_tokens for s in seqs], r[0].float().cpu())), r)[1])(_r(seqs, prefill))
+        outs.append([o["token_ids"] for o in engine.generate(prompts, sp, use_tqdm=False)])
+        logits.append(seen)
+        engine.exit()
+    assert outs[0] == outs[1]
+    one_shot = [x for x in logits[0] if x[0]]
+    chunked = [x for x in logits[1] if x[0]]
+    assert [x[1] for x in chunked][:3] == [[128], [128], [44]]            # the long prompt: three chunks, alone
+    # last-token logits of the long prompt: final chunk vs the one-shot prefill row of the same sequence
+    torch.testing.assert_close(chunked[2][2][0], one_shot[0][2][0], rtol=2e-2, atol=2e-2)
+
+
 def test_kv_pool_sized_by_hbm_not_by_the_cap(tmp_path):
     """a10 on the real part: num_kvcache_blocks=-1 with limits so large (max_num_seqs 512 x max_model_len 40960 =
     327 680 blocks = 2.2 TiB of Qwen3-1.7B KV) that the 288 GB of HBM, not the cap, decide.  The pool must fit the

@@ -259,3 +259,60 @@ def test_block_manager_errors_and_may_append_boundaries():
     t = Sequence([9, 9, 9, 9, 9], block_size=4)
     bm.allocate(t)
     assert blk.hash != BlockManager.compute_hash([1, 2, 3, 4]) or blk.block_id not in t.block_table
+
+
+# ---------------------------------------------------------------- chunked prefill (beyond the reference, §8 f4)
+def test_chunked_prefill_schedule_and_inputs():
+    """A 300-token prompt with a 128-token step budget: three prefill steps of 128 / 128 / 44 tokens, each naming
+    the whole prefix as keys (cu_k) and only its own tokens as queries / slots; nothing else is scheduled in
+    between; only the last chunk's token becomes a token.  Short prompts schedule exactly as without the flag."""
+    cfg = SimpleNamespace(max_num_seqs=4, max_num_batched_tokens=128, eos=-1, num_kvcache_blocks=16,
+                          kvcache_block_size=64, max_model_len=512, enable_chunked_prefill=True)
+    sched = Scheduler(cfg)
+    builder = InputBuilder(64, 4, 512, 128)
+    long_seq = Sequence(list(range(1, 301)), SamplingParams(max_tokens=3, ignore_eos=True), block_size=64)
+    short = Sequence([7, 8, 9], SamplingParams(max_tokens=2, ignore_eos=True), block_size=64)
+    sched.add(long_seq)
+    sched.add(short)
+    spans = []
+    for step in range(3):
+        batch, is_prefill = sched.schedule()
+        assert is_prefill and batch == [long_seq]
+        inp = builder.prefill(batch)
+        lo, hi = long_seq.num_cached_tokens, long_seq.prefill_stop
+        spans.append((lo, hi))
+        assert inp.input_ids.tolist() == list(range(1 + lo, 1 + hi))
+        assert inp.positions.tolist() == list(range(lo, hi))
+        assert inp.cum_seqlens_q.tolist() == [0, hi - lo] and inp.cum_seqlens_k.tolist() == [0, hi]
+        assert (inp.max_seqlen_q, inp.max_seqlen_k) == (hi - lo, hi)
+        want_slots = [long_seq.block_table[p // 64] * 64 + p % 64 for p in range(lo, hi)]
+        assert inp.slot_mapping.tolist() == want_slots
+        assert inp.block_tables.tolist() == [long_seq.block_table]
+        sched.postprocess(batch, [11])
+    assert spans == [(0, 128), (128, 256), (256, 300)]
+    assert long_seq.token_ids[-1] == 11 and len(long_seq) == 301 and long_seq.prefill_end is None
+    assert sched.prefilling is None and list(sched.running) == [long_seq]
+    batch, is_prefill = sched.schedule()              # now the short prompt, as usual
+    assert is_prefill and batch == [short]
+    sched.postprocess(batch, [5])
+    batch, is_prefill = sched.schedule()
+    assert not is_prefill and batch == [long_seq, short]
+    # without the flag the same prompt is what the reference makes of it: never schedulable
+    cfg.enable_chunked_prefill = False
+    s2 = Scheduler(cfg)
+    s2.add(Sequence(list(range(1, 301)), block_size=64))
+    with pytest.raises(RuntimeError, match="No sequences scheduled"):
+        s2.schedule()
+
+
+def test_chunked_prefill_config_gate(tmp_path):
+    from minivllm_amd.config import Config
+
+    (tmp_path / "config.json").write_text(json.dumps(dict(
+        model_type="qwen3", architectures=["Qwen3ForCausalLM"], hidden_size=64, num_hidden_layers=1,
+        num_attention_heads=2, num_key_value_heads=1, head_dim=32, intermediate_size=64, vocab_size=100,
+        max_position_embeddings=4096, rms_norm_eps=1e-6, tie_word_embeddings=True, hidden_act="silu")))
+    with pytest.raises(ValueError, match="max_num_batched_tokens"):      # the reference's rule, by default
+        Config(str(tmp_path), max_num_batched_tokens=1024, max_model_len=4096)
+    cfg = Config(str(tmp_path), max_num_batched_tokens=1024, max_model_len=4096, enable_chunked_prefill=True)
+    assert cfg.max_model_len == 4096

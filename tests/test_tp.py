@@ -206,6 +206,64 @@ def test_tp2_logits_match_reference_on_one_gpu(golden_dir, tmp_path):
         assert r["greedy_ok"], r
 
 
+# ---------------------------------------------------------------------------------- sharded checkpoint loading (CPU)
+def _sharded_load_worker(rank, world, port, golden, ckpt_dir, out_path):
+    """every rank reads from the safetensors file only the slices it owns (LazyTensor), and ends up
+    with exactly the shard the reference's loaders would cut from the whole tensor."""
+    _init(rank, world, port)
+    from transformers import AutoConfig
+
+    from minivllm_amd.glue import create_model
+    from minivllm_amd.utils.loader import LazyTensor, load_model
+
+    z = np.load(golden)
+    full = {k[2:]: torch.from_numpy(z[k].view(np.int16).copy()).view(torch.bfloat16).float() for k in z.files if k.startswith("w:")}
+    model = create_model(AutoConfig.from_pretrained(ckpt_dir))
+    LazyTensor.bytes_read = 0
+    load_model(model, ckpt_dir)
+    total = sum(v.numel() * 2 for v in full.values())          # the file holds bf16
+    errs = []
+    l0 = model.model.layers[0]
+    H, Hkv, D = 4, 2, 128
+    qs, ks = H * D // world, Hkv * D // world
+    p = "model.layers.0.self_attn."
+    want_qkv = torch.cat([full[p + "q_proj.weight"][rank * qs:(rank + 1) * qs], full[p + "k_proj.weight"][rank * ks:(rank + 1) * ks],
+                          full[p + "v_proj.weight"][rank * ks:(rank + 1) * ks]])
+    errs.append(torch.equal(l0.self_attn.qkv_proj.weight.data.float(), want_qkv))
+    o_full = full[p + "o_proj.weight"]
+    cols = o_full.shape[1] // world
+    errs.append(torch.equal(l0.self_attn.o_proj.weight.data.float(), o_full[:, rank * cols:(rank + 1) * cols]))
+    inter = full["model.layers.0.mlp.gate_proj.weight"].shape[0] // world
+    want_gu = torch.cat([full["model.layers.0.mlp.gate_proj.weight"][rank * inter:(rank + 1) * inter],
+                         full["model.layers.0.mlp.up_proj.weight"][rank * inter:(rank + 1) * inter]])
+    errs.append(torch.equal(l0.mlp.gate_up_proj.weight.data.float(), want_gu))
+    emb = full["model.embed_tokens.weight"]
+    rows = emb.shape[0] // world
+    errs.append(torch.equal(model.model.embed_tokens.weight.data.float(), emb[rank * rows:(rank + 1) * rows]))
+    errs.append(torch.equal(l0.input_layernorm.weight.data.float(), full["model.layers.0.input_layernorm.weight"]))   # replicated
+    # the sharded matrices are >95 % of this checkpoint: a rank must have read about half of the bytes, not all
+    errs.append(0.45 * total < LazyTensor.bytes_read < 0.60 * total)
+    dist.barrier()
+    open(out_path + f".{rank}", "w").write("ok" if all(errs) else f"bad {errs} read {LazyTensor.bytes_read} of {total}")
+    dist.destroy_process_group()
+
+
+def test_sharded_direct_load_reads_only_own_slices(golden_dir, tmp_path):
+    from safetensors.torch import save_file
+
+    golden = os.path.join(golden_dir, "e2e_qwen3.npz")
+    z = np.load(golden)
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    (d / "config.json").write_text(bytes(z["config_json"]).decode())
+    save_file({k[2:]: torch.from_numpy(z[k].view(np.int16).copy()).view(torch.bfloat16).contiguous()
+               for k in z.files if k.startswith("w:")}, str(d / "model.safetensors"))
+    out = str(tmp_path / "res")
+    mp.spawn(_sharded_load_worker, args=(2, _free_port(), golden, str(d), out), nprocs=2, join=True)
+    for rank in (0, 1):
+        assert open(out + f".{rank}").read() == "ok"
+
+
 # ---------------------------------------------------------------------------------- config 5 shapes, world 8 (CPU)
 def _config5_worker(rank, world, port, out_path):
     """BASELINE config 5: Qwen2-72B-Instruct, TP = 8.  Head split 64/8 -> 8/1 per rank, vocab 152064/8,
