@@ -167,7 +167,7 @@ def decode_roofline(engine, args):
     # HBM traffic from the PMC counters (separate rocprofv3 --pmc passes, corrected as the microarch guide
     # prescribes): measured on the same kernel / head layout at B=256, ctx=1024 and scaled by bytes
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_decode.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_decode.json")
     if os.path.exists(pmc) and args.gpus == 1:
         with open(pmc) as f:
             for name, rec in json.load(f)["kernels"].items():
@@ -178,7 +178,7 @@ def decode_roofline(engine, args):
               else "paged_decode_kernel")
     return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": "profiles/r01_pmc_decode.json (PMC FETCH_SIZE x2 + WRITE_SIZE, per launch, scaled to this run's context)" if traffic else None,
+            "traffic_source": "profiles/r02_pmc_decode.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes on this kernel and head layout at B=256 ctx=1024, per launch, scaled to this run's context; counters cannot be read inside a timed run)" if traffic else None,
             "bytes_per_launch": algo, "us_per_launch": round(sec * 1e6, 2), "launches_timed": len(kept),
             "launches_discarded_host_stall": len(times) - len(kept)}
 

@@ -329,6 +329,78 @@ def test_kv_cache_auto_sizing_and_graph_buckets(golden_dir, tmp_path):
     assert graph_batch_sizes(1) == [1]
 
 
+def test_config5_per_gpu_layer_shape_qwen2_72b_tp8(tmp_path):
+    """BASELINE config 5 as far as one GPU goes: the PER-GPU shard of Qwen2-72B at TP = 8 — hidden 8192, 8 query
+    heads / 1 kv head of 128, intermediate 29568 / 8 = 3696, qkv bias — as a 2-layer model (no collectives: what a
+    rank computes between its all-reduces), bf16, against the fp32 oracle on the same seeded weights: prefill of
+    three prompts, then decode steps at a batch that takes the decode-batch projection kernels (40 rows; down_proj's
+    K = 3696 is not a multiple of 64 and stays on the library GEMM).  Bound: 2.5 % of the logit scale (bf16 through
+    two 8192-wide layers against fp32 math; the measured error is printed)."""
+    import golden_inputs as GI
+    from oracle.model import OracleModel
+
+    from minivllm_amd.config import Config
+    from minivllm_amd.engine.block_manager import BlockManager
+    from minivllm_amd.engine.inference_executor import InferenceExecutor
+    from minivllm_amd.engine.input_builder import InputBuilder
+    from minivllm_amd.engine.sequence import Sequence
+    from minivllm_amd.glue import create_model
+    from minivllm_amd.sampling_params import SamplingParams
+
+    cfg_d = dict(model_type="qwen2", architectures=["Qwen2ForCausalLM"], hidden_size=8192, num_hidden_layers=2,
+                 num_attention_heads=8, num_key_value_heads=1, head_dim=128, intermediate_size=3696, vocab_size=2048,
+                 max_position_embeddings=4096, rms_norm_eps=1e-6, rope_theta=1000000.0, tie_word_embeddings=False,
+                 hidden_act="silu", torch_dtype="bfloat16")
+    (tmp_path / "config.json").write_text(json.dumps(cfg_d))
+    hfw = GI.seeded_hf_weights(cfg_d, seed=5)
+    nseq = 40
+    cfg = Config(str(tmp_path), num_kvcache_blocks=3 * nseq, max_model_len=192, max_num_batched_tokens=4096,
+                 max_num_seqs=64, enforce_eager=True, dtype="bfloat16")
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(DEV):
+            model = create_model(cfg.hf_config)
+    finally:
+        torch.set_default_dtype(prev)
+    model.load_weights({k: v.float() for k, v in hfw.items()})
+    model = model.to(device=DEV, dtype=torch.bfloat16)
+    for mod in model.modules():                      # what ModelManager does after loading
+        if hasattr(mod, "pack_for_decode"):
+            mod.pack_for_decode()
+    att = model.model.layers[0].self_attn
+    assert (att.num_heads, att.num_kv_heads, att.head_dim) == (8, 1, 128) and att.qkv_proj.weight.shape == (1280, 8192)
+    assert att.qkv_proj.weight_packed is not None and model.model.layers[0].mlp.down_proj.weight_packed is None
+    ex = InferenceExecutor(cfg, model, torch.device(DEV))
+    ex._allocate_kv_cache(); ex._initialize_sampler(); ex._optimize_model()
+    ref = OracleModel(cfg_d, {k: v.float() for k, v in hfw.items()}, torch.float32, num_blocks=3 * nseq)
+    g = torch.Generator().manual_seed(0)
+    greedy = SamplingParams(temperature=0.0, max_tokens=64, ignore_eos=True)
+    seqs = [Sequence(torch.randint(0, 2048, (int(n),), generator=g).tolist(), greedy, block_size=64)
+            for n in torch.randint(3, 100, (nseq,), generator=g)]
+    bm, ib = BlockManager(3 * nseq, 64), InputBuilder(64, 64, 192, 4096)
+    for s in seqs:
+        bm.allocate(s)
+    worst = 0.0
+    for step in range(3):
+        prefill = step == 0
+        inp = ib.prefill(seqs) if prefill else ib.decode(seqs)
+        meta = dict(is_prefill=prefill, slot_mapping=inp.slot_mapping, block_tables=inp.block_tables,
+                    cu_q=inp.cum_seqlens_q, cu_k=inp.cum_seqlens_k, context_lens=inp.context_lens)
+        want = ref.forward_logits(inp.input_ids.clone(), inp.positions.clone(), meta).float()
+        got, _ = ex.execute_batch(seqs, prefill=prefill)
+        got = got.float().cpu()
+        scale = want.abs().max().item()
+        err = (got - want).abs().max().item()
+        worst = max(worst, err / scale)
+        assert err <= 0.025 * scale, f"step {step}: err {err:.4f} scale {scale:.3f}"
+        assert torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item() > 0.9995
+        for s, t in zip(seqs, want.argmax(-1).tolist()):
+            s.append_token(int(t))
+            bm.may_append(s)
+    print(f"\nconfig 5 per-GPU shard (hidden 8192, 8/1 heads, inter 3696), bf16 vs fp32 oracle: worst error {worst:.4%} of the logit scale")
+
+
 def test_chunked_prefill_equals_one_shot_prefill(golden_dir, tmp_path):
     """SURVEY §8 f4 / BASELINE config 4: a 300-token prompt prefilled in chunks of 128 (each chunk attends the
     earlier ones through the paged cache) must produce the logits of the one-shot prefill, and the same greedy

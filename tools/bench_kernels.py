@@ -22,7 +22,7 @@ def timeit(fn, iters=20, warmup=3):
     return s.elapsed_time(e) / iters * 1e-3
 
 
-def bench_decode(B, Hq, Hkv, D, ctx, bs=64, dtype=torch.bfloat16, layers=4):
+def bench_decode(B, Hq, Hkv, D, ctx, bs=64, dtype=torch.bfloat16, layers=4, flags=None):
     nblk = (ctx + bs - 1) // bs
     nb = B * nblk
     # several "layers" of cache so that successive launches do not hit in the 256 MiB Infinity Cache
@@ -37,11 +37,11 @@ def bench_decode(B, Hq, Hkv, D, ctx, bs=64, dtype=torch.bfloat16, layers=4):
     def fn():
         k, v = caches[state["i"] % layers]
         state["i"] += 1
-        H.paged_decode(q, k, v, table, cl, D ** -0.5, out=out)
+        H.paged_decode(q, k, v, table, cl, D ** -0.5, out=out, flags=flags)
     t = timeit(fn)
     esz = 2 if dtype != torch.float32 else 4
     bytes_ = B * ctx * 2 * Hkv * D * esz + 2 * B * Hq * D * esz + B * nblk * 4
-    print(f"paged_decode B={B} H={Hq}/{Hkv} D={D} ctx={ctx}: {t*1e6:8.1f} us  {bytes_/t/1e9:8.1f} GB/s  ({bytes_/1e6:.1f} MB)")
+    print(f"paged_decode B={B} H={Hq}/{Hkv} D={D} ctx={ctx} flags={flags}: {t*1e6:8.1f} us  {bytes_/t/1e9:8.1f} GB/s  ({bytes_/1e6:.1f} MB)")
     return t, bytes_
 
 
@@ -72,9 +72,21 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--prefill-only", action="store_true")
+    ap.add_argument("--decode-ab", action="store_true", help="paged decode shapes, warmed up and repeated")
     ap.add_argument("--variants", default="0", help="prefill kernel bench variants (flags >> 4), comma separated")
     a = ap.parse_args()
     print(torch.cuda.get_device_name(0))
+    if a.decode_ab:
+        for _ in range(2):
+            bench_decode(256, 16, 8, 128, 1024)
+        print("--- (warm-up above) ---")
+        for rep in range(3):
+            for fl in (0,):   # (round 2: an XCD-aware grid order, flag 16, was tried here: 172 -> 173 us, dropped)
+                bench_decode(256, 16, 8, 128, 1024, flags=fl)
+                bench_decode(256, 28, 4, 128, 1024, flags=fl)
+                bench_decode(256, 8, 1, 128, 1024, flags=fl)
+                bench_decode(64, 16, 8, 128, 4096, layers=2, flags=fl)
+        raise SystemExit(0)
     if a.prefill_only:
         # the chip's clock ramps over the first second of load: warm up, then interleave the variants and repeat
         for _ in range(3):
