@@ -153,13 +153,25 @@ __global__ void __launch_bounds__((WM * WN + NLX + NLW) * 64) linear_mid_m_kerne
         }
         src[j] = (const T *)p.wp + ((int64_t)n16 * kfrags + ks) * 512 + lane * 8;
       }
+      // cache policy: a weight tile that ONE workgroup streams is read once -> non-temporal; with several row
+      // tiles the other workgroups of the tile (same XCD, ids equal mod 8) may find the line in the L2: default
+      // policy (PMC FETCH_SIZE: -12 % fabric reads on 128x128 tiles, -1 % on 64x64; most repeats still miss the
+      // 4 MiB L2 and come from the Infinity Cache; launch times unchanged, profiles/r02_pmc_mid_m.json)
+      const bool once = p.m_tiles == 1;
       auto issue = [&](int i, int slot) {
         char *dst = wl + slot * WS + lw2 * 1024;
         const int koff = kb_of(i) * 1024;   // 2 fragments of 512 elements per k-block
+        if (once) {
 #pragma unroll
-        for (int j = 0; j < PW; ++j)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[j] + koff),
-                                           (__attribute__((address_space(3))) void *)(dst + j * NLW * 1024), 16, 0, 2);
+          for (int j = 0; j < PW; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[j] + koff),
+                                             (__attribute__((address_space(3))) void *)(dst + j * NLW * 1024), 16, 0, 2);
+        } else {
+#pragma unroll
+          for (int j = 0; j < PW; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[j] + koff),
+                                             (__attribute__((address_space(3))) void *)(dst + j * NLW * 1024), 16, 0, 0);
+        }
       };
 #pragma unroll
       for (int s = 0; s < SW - 1; ++s)
