@@ -295,6 +295,21 @@ int mv_greedy_pack(const void *logits_local, int64_t ld, const int64_t *local_to
 int mv_greedy_merge(const void *buf, int world, int rows, int rows_padded,
                     int64_t *tokens, int dtype, void *stream);
 
+/* f2 — SAMPLED decoding under tensor parallelism without the logit all-gather, for rows that are greedy or whose
+ * top_k is in 1..mv_topc_width() (= 64; replaces, for such batches, the gather of ParallelLMHead.forward,
+ * minivllm/models/layers/embed_head.py:219-229, in front of Sampler.forward, sampling/sampler.py:84-110).
+ * mv_topc_pack: buf [world][rows_padded][64][4] (16-bit dtype) <- zeros, except slot [rank][r][c] = the c-th of the
+ *   64 largest logits of this rank's vocab shard of row r (shard-visiting order, deterministic) as
+ *   (logit, three 8-bit pieces of its GLOBAL index), all exact; shards shorter than 64 pad with (-inf, 0).
+ * After an exact sum all-reduce of buf (mv_ar_all_reduce), mv_topc_unpack writes cand_logits [rows][world*64] and
+ * cand_idx int32 [rows][world*64]; mv_sample on cand_logits draws a candidate position, cand_idx maps it back.
+ * The union of the per-rank candidates holds a complete top-k set, and top-p / min-p / the draw only look at that. */
+int mv_topc_width(void);
+int mv_topc_pack(const void *logits_local, int64_t ld, int vocab_local, int rank, int world,
+                 int64_t vocab_per_rank, int rows, int rows_padded, void *buf, int dtype, void *stream);
+int mv_topc_unpack(const void *buf, int world, int rows, int rows_padded, void *cand_logits,
+                   int32_t *cand_idx, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

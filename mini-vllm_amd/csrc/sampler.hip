@@ -606,6 +606,112 @@ __global__ void __launch_bounds__(kThreads) sample_kernel(SampleParams p) {
   }
 }
 
+
+// f2 for SAMPLED rows under tensor parallelism: instead of all-gathering [B, V/tp] logits, every
+// rank reduces its vocab shard of a row to its kTopC largest logits (+ their global indices).  For a row whose
+// top_k is in 1..kTopC (or that is greedy) the union of the per-rank candidates contains a complete top-k set, the
+// filters after it (top-p, min-p) and the draw only ever look at that set, so running the ordinary sampler on the
+// gathered [B, world * kTopC] candidates is the exact distribution of the full-row sampler (ties at the k-th value
+// may be resolved towards other, equal-valued tokens).  The exchange format is the greedy path's: 16-bit floats that
+// are exact (the logit itself, three 8-bit pieces of the global index) in slot [rank] of a zeroed buffer, summed by
+// the peer-to-peer all-reduce (x + 0 = x): no backend collective, so the decode step stays graph-capturable.
+constexpr int kTopC = 64;
+
+template <typename Tag>
+__global__ void __launch_bounds__(kThreads) topc_pack_kernel(const uint16_t *logits, int64_t ld, int vocab_local, int rank,
+                                                             int world, int64_t vocab_per_rank, int rows_padded,
+                                                             uint16_t *buf) {
+  typedef uint16_t T;
+  __shared__ Shared sh;
+  const int rowi = blockIdx.x;
+  const T *row = logits + (int64_t)rowi * ld;
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+  // my slots <- (-inf, 0, 0, 0), every other rank's slots of this row <- 0
+  const uint32_t ninf = elem<Tag>::st(-INFINITY);
+  for (int i = threadIdx.x; i < world * kTopC; i += kThreads) {
+    const int q = i / kTopC, c = i - q * kTopC;
+    u32x2 w = {0u, 0u};
+    if (q == rank) w[0] = ninf;
+    *(u32x2 *)(buf + (((int64_t)q * rows_padded + rowi) * kTopC + c) * 4) = w;
+  }
+  // the kTopC-th largest key of the shard: two 8-bit radix levels over LDS count histograms
+  const unsigned want = (unsigned)min(kTopC, vocab_local);
+  uint32_t prefix = 0;
+  unsigned above = 0, bin_count = 0;
+  for (int lvl = 0; lvl < 2; ++lvl) {
+    const int shift = 16 - 8 * (lvl + 1);
+    __syncthreads();
+    if (threadIdx.x < 256) sh.ihist[threadIdx.x] = 0;
+    __syncthreads();
+    row_foreach<Tag>(row, vocab_local, vec_ok, [&](int i, T raw, bool ok) {
+      const uint32_t key = make_key<Tag>(raw);
+      const bool in = ok && (lvl == 0 || (key >> (shift + 8)) == prefix);
+      hist_add<unsigned>(sh.ihist, in, (key >> shift) & 0xffu, 1u);
+    });
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned c = above;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (c + sh.ihist[d] >= want) break;
+        c += sh.ihist[d];
+      }
+      sh.bcast_u[0] = (unsigned)d;
+      sh.bcast_u[1] = c;
+      sh.bcast_u[2] = sh.ihist[d];
+    }
+    __syncthreads();
+    prefix = (prefix << 8) | sh.bcast_u[0];
+    above = sh.bcast_u[1];
+    bin_count = sh.bcast_u[2];
+  }
+  const uint32_t key_k = prefix;
+  const unsigned need_ties = want - above;   // of the bin_count elements equal to the threshold
+  (void)bin_count;
+  // deterministic compaction in visiting order: count, scan, write
+  unsigned my_gt = 0, my_tie = 0;
+  row_foreach<Tag>(row, vocab_local, vec_ok, [&](int i, T raw, bool ok) {
+    const uint32_t key = make_key<Tag>(raw);
+    my_gt += ok && key > key_k;
+    my_tie += ok && key == key_k;
+  });
+  unsigned tot;
+  unsigned gt_at = block_exscan_u(my_gt, tot, sh);
+  unsigned tie_at = block_exscan_u(my_tie, tot, sh);
+  uint16_t *mine = buf + ((int64_t)rank * rows_padded + rowi) * kTopC * 4;
+  __syncthreads();   // the fill above is complete before the candidates overwrite it
+  row_foreach<Tag>(row, vocab_local, vec_ok, [&](int i, T raw, bool ok) {
+    if (!ok) return;
+    const uint32_t key = make_key<Tag>(raw);
+    int slot = -1;
+    if (key > key_k) slot = (int)gt_at++;
+    else if (key == key_k) {
+      const unsigned t = tie_at++;
+      if (t < need_ties) slot = (int)(above + t);
+    }
+    if (slot >= 0 && slot < kTopC) {
+      const int64_t g = (int64_t)rank * vocab_per_rank + i;
+      u32x2 w;
+      w[0] = (uint32_t)raw | ((uint32_t)elem<Tag>::st((float)((g >> 16) & 255)) << 16);
+      w[1] = (uint32_t)elem<Tag>::st((float)((g >> 8) & 255)) | ((uint32_t)elem<Tag>::st((float)(g & 255)) << 16);
+      *(u32x2 *)(mine + (int64_t)slot * 4) = w;
+    }
+  });
+}
+
+template <typename Tag>
+__global__ void topc_unpack_kernel(const uint16_t *buf, int world, int rows, int rows_padded, uint16_t *cand_logits,
+                                   int32_t *cand_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over rows * world * kTopC
+  const int per_row = world * kTopC;
+  if (i >= rows * per_row) return;
+  const int r = i / per_row, j = i - r * per_row, q = j / kTopC, c = j - q * kTopC;
+  const u32x2 w = *(const u32x2 *)(buf + (((int64_t)q * rows_padded + r) * kTopC + c) * 4);
+  cand_logits[i] = (uint16_t)(w[0] & 0xffffu);
+  cand_idx[i] = ((int32_t)elem<Tag>::ld((uint16_t)(w[0] >> 16)) << 16) | ((int32_t)elem<Tag>::ld((uint16_t)(w[1] & 0xffffu)) << 8) |
+                (int32_t)elem<Tag>::ld((uint16_t)(w[1] >> 16));
+}
+
 }  // namespace
 
 extern "C" size_t mv_sample_workspace_bytes(int batch, int vocab) {
@@ -628,6 +734,44 @@ extern "C" int mv_sample(const void *logits, int64_t ld, const float *temperatur
   p.offset_dev = offset_dev; p.out_tokens = out_tokens; p.keep_mask = keep_mask; p.vocab = vocab;
   MV_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sample_kernel<Tag>), dim3(batch), dim3(kThreads), 0,
                                               (hipStream_t)stream, p));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_topc_width(void) { return kTopC; }
+
+extern "C" int mv_topc_pack(const void *logits_local, int64_t ld, int vocab_local, int rank, int world,
+                            int64_t vocab_per_rank, int rows, int rows_padded, void *buf, int dtype, void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!logits_local || !buf) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (rows < 0 || rows_padded < rows || world < 1 || rank < 0 || rank >= world || vocab_local <= 0 || ld < vocab_local ||
+      vocab_per_rank * world > (1 << 24))
+    return MV_E_SHAPE;
+  if (((uintptr_t)buf) & 7u) return MV_E_ALIGN;
+  if (dtype == MV_BF16)
+    hipLaunchKernelGGL((topc_pack_kernel<bf16_tag>), dim3(rows), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint16_t *)logits_local, ld, vocab_local, rank, world, vocab_per_rank, rows_padded, (uint16_t *)buf);
+  else
+    hipLaunchKernelGGL((topc_pack_kernel<f16_tag>), dim3(rows), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint16_t *)logits_local, ld, vocab_local, rank, world, vocab_per_rank, rows_padded, (uint16_t *)buf);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_topc_unpack(const void *buf, int world, int rows, int rows_padded, void *cand_logits, int32_t *cand_idx,
+                              int dtype, void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!buf || !cand_logits || !cand_idx) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (rows < 0 || rows_padded < rows || world < 1) return MV_E_SHAPE;
+  const int n = rows * world * kTopC;
+  if (dtype == MV_BF16)
+    hipLaunchKernelGGL((topc_unpack_kernel<bf16_tag>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)buf, world, rows, rows_padded, (uint16_t *)cand_logits, cand_idx);
+  else
+    hipLaunchKernelGGL((topc_unpack_kernel<f16_tag>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)buf, world, rows, rows_padded, (uint16_t *)cand_logits, cand_idx);
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

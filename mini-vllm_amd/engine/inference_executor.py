@@ -22,7 +22,7 @@ import torch
 from ..config import Config
 from ..layers.sampler import Sampler
 from ..parallel_state import (decode_step_is_native, get_custom_all_reduce as get_custom_allreduce,
-                              get_tensor_parallel_world_size, tp_greedy_tokens)
+                              get_tensor_parallel_world_size, tp_candidate_tokens, tp_greedy_tokens)
 from ..utils.context import reset_context, set_context
 from .. import hip_ops
 from .input_builder import BatchInputs, InputBuilder
@@ -69,6 +69,8 @@ class InferenceExecutor:
         self.sampler: Sampler | None = None
         self.graphs: dict[int, torch.cuda.CUDAGraph] = {}
         self.greedy_graphs: dict[int, torch.cuda.CUDAGraph] = {}   # TP > 1: per-rank argmax instead of the logit gather
+        self.cand_graphs: dict[int, torch.cuda.CUDAGraph] = {}     # TP > 1: per-rank top-64 candidates (sampled rows with 1 <= top_k <= 64)
+        self._cand_capture = "no"                                  # "no" | "lazy" | "done"
         self.graph_bs: list[int] = []
         self.graph_vars: dict[str, torch.Tensor] = {}
         self.graph_pool = None
@@ -201,9 +203,9 @@ class InferenceExecutor:
                 self._drop_speculation()  # a speculative decode step in flight (if any) is simply ignored
                 inp = self.builder.prefill(sequences)
                 ids, pos = self._ship_prefill(inp, sequences)
-                greedy = self._tp_greedy(sequences)
-                logits = self.model.compute_logits(self.model(ids, pos), gather=not greedy)
-                tokens = self._sample_tokens(logits, sequences, tp_greedy=greedy)
+                mode = self._tp_mode(sequences)
+                logits = self.model.compute_logits(self.model(ids, pos), gather=mode == "gather")
+                tokens = self._sample_tokens(logits, sequences, mode)
             else:
                 bs = self._graph_bucket(sequences)
                 inp = self.builder.decode(sequences, pad_to=bs)
@@ -213,9 +215,9 @@ class InferenceExecutor:
                 else:
                     self._drop_speculation()
                     ids, pos = self._ship_decode(inp)
-                    greedy = self._tp_greedy(sequences)
-                    logits = self.model.compute_logits(self.model(ids, pos), gather=not greedy)
-                    tokens = self._sample_tokens(logits, sequences, tp_greedy=greedy)
+                    mode = self._tp_mode(sequences)
+                    logits = self.model.compute_logits(self.model(ids, pos), gather=mode == "gather")
+                    tokens = self._sample_tokens(logits, sequences, mode)
             self._check_peer_waits(eager)
             self._update_metrics(sequences, prefill)
             self.inference_count += 1
@@ -289,13 +291,30 @@ class InferenceExecutor:
     def _tp_greedy(self, sequences) -> bool:
         return self.tp_size > 1 and self.sampler is not None and all(s.temperature == 0 for s in sequences)
 
+    def _tp_mode(self, sequences) -> str:
+        """How a tensor-parallel batch gets its tokens: 'greedy' (per-rank argmax merge), 'cand' (per-rank top-64
+        candidates: every row greedy or with 1 <= top_k <= 64, 16-bit logits) or 'gather' (all-gather of the
+        [B, V/tp] logits: everything else).  TP = 1: 'gather' (the plain sampler on the full row)."""
+        if self.tp_size == 1 or self.sampler is None:
+            return "gather"
+        if all(s.temperature == 0 for s in sequences):
+            return "greedy"
+        if self.dtype in (torch.bfloat16, torch.float16) and self.config.hf_config.vocab_size <= 1 << 24 and all(
+                s.temperature == 0 or 0 < s.top_k <= hip_ops.TOPC for s in sequences):
+            return "cand"
+        return "gather"
+
+    def _cand_tokens(self, logits_local, t, k, p, m):
+        """'cand' mode, eager: the sampler (one Philox step, like any other batch) on the gathered candidates."""
+        return tp_candidate_tokens(logits_local, lambda cl: self.sampler(cl, temperatures=t, top_ks=k, top_ps=p, min_ps=m))
+
     def _greedy_merge(self, logits_local, t, k, p, m):
         """Tokens of an all-greedy batch from this rank's vocab shard (temperature 0 rows: the sampler
         kernel returns the lowest-index argmax of the shard)."""
         local = self.sampler(logits_local, temperatures=t, top_ks=k, top_ps=p, min_ps=m)
         return tp_greedy_tokens(logits_local, local)
 
-    def _sample_tokens(self, logits, sequences, tp_greedy: bool = False) -> list[int]:
+    def _sample_tokens(self, logits, sequences, mode: str = "gather") -> list[int]:
         if self.sampler is None:
             return []
         if len(sequences) > self._samp_i64.shape[0]:
@@ -306,8 +325,10 @@ class InferenceExecutor:
             m = torch.tensor([s.min_p for s in sequences], dtype=torch.float32, device=dev)
         else:
             t, k, p, m = self._ship_sampling(sequences)
-        if tp_greedy:
+        if mode == "greedy":
             return self._greedy_merge(logits, t, k, p, m).tolist()
+        if mode == "cand":
+            return self._cand_tokens(logits, t, k, p, m).tolist()
         return self.sampler(logits, temperatures=t, top_ks=k, top_ps=p, min_ps=m).tolist()
 
     def _update_metrics(self, sequences, prefill: bool) -> None:
@@ -322,13 +343,27 @@ class InferenceExecutor:
         """Smallest captured bucket that holds the batch, in the graph family the batch decodes with."""
         if self.enforce_eager:
             return None
-        greedy = bool(self.greedy_graphs) and self._tp_greedy(sequences)
-        if not greedy and self._general_capture == "lazy":
+        family = self._graph_family(sequences, capture=True)[1]
+        return next((bs for bs in self.graph_bs if bs >= len(sequences) and bs in family), None)
+
+    def _graph_family(self, sequences, capture: bool = False):
+        """-> (mode, graphs of the family this batch decodes with).  The candidate family and (under TP) the
+        gathered-logits family are captured on first use."""
+        mode = self._tp_mode(sequences)
+        if mode == "greedy" and self.greedy_graphs:
+            return "greedy", self.greedy_graphs
+        if mode == "cand" and self._cand_capture != "no":
+            if self._cand_capture == "lazy" and capture:
+                self._drop_speculation()
+                torch.cuda.synchronize(self.device)
+                self._capture_cand()
+            if self.cand_graphs:
+                return "cand", self.cand_graphs
+        if capture and self._general_capture == "lazy":
             self._drop_speculation()
             torch.cuda.synchronize(self.device)
             self._capture_general()
-        family = self.greedy_graphs if greedy else self.graphs
-        return next((bs for bs in self.graph_bs if bs >= len(sequences) and bs in family), None)
+        return "gather", self.graphs
 
     def capture_device_graphs(self, max_batch_size: int) -> None:
         """Capture one hipGraph per decode batch-size bucket (largest first, shared pool)."""
@@ -374,6 +409,8 @@ class InferenceExecutor:
             if self.tp_size > 1:   # the family without a backend collective inside (peer-to-peer kernels only)
                 for bs in reversed(self.graph_bs):
                     self._capture_one(bs, greedy=True)
+                if self.greedy_graphs and decode_step_is_native(self.dtype, hf.hidden_size, hf.vocab_size):
+                    self._cand_capture = "lazy"   # same property: only this library's kernels inside (first use captures)
                 if general_ok and self.greedy_graphs and decode_step_is_native(self.dtype, hf.hidden_size, hf.vocab_size):
                     # the gathered-logits family needs RCCL nodes in its graphs: captured on the first batch with
                     # a sampled row (_graph_bucket), so that a greedy-only workload never captures a collective
@@ -386,13 +423,16 @@ class InferenceExecutor:
             logger.warning("Failed to capture device graphs, decoding eagerly: %s", e)
             self.graphs.clear()
             self.greedy_graphs.clear()
+            self.cand_graphs.clear()
             self.graph_pool = None
-            self._general_capture = "no"
+            self._general_capture = self._cand_capture = "no"
             self._recover_from_failed_capture()
 
     def _capture_general(self) -> None:
         """The gathered-logits graphs (every sampling mode).  Under TP a failure here only sends batches with
         sampled rows to eager decoding: the all-greedy graphs stay."""
+        if self._general_capture == "lazy":
+            self._neutralise_graph_inputs()
         try:
             for bs in reversed(self.graph_bs):
                 self._capture_one(bs, greedy=False)
@@ -405,6 +445,32 @@ class InferenceExecutor:
             self._general_capture = "no"
             self._recover_from_failed_capture()
 
+    def _neutralise_graph_inputs(self) -> None:
+        """Before a capture that happens while sequences are LIVE (the lazily captured families): the warm-up and
+        capture runs execute the model on whatever the graph inputs hold, and a stale slot (0 after start-up) would
+        overwrite a live sequence's K/V row.  Slot -1 rows store nothing and context 0 rows read nothing — the
+        replay-padding convention (reference inference_executor.py:758-764); the next real replay rewrites the
+        whole input pack from the host."""
+        gv = self.graph_vars
+        gv["slot_mapping"].fill_(-1)
+        gv["context_lens"].zero_()
+        gv["input_ids"].zero_()
+        gv["positions"].zero_()
+        torch.cuda.synchronize(self.device)
+
+    def _capture_cand(self) -> None:
+        """The per-rank-candidates graphs (batches of greedy / small-top-k rows under TP)."""
+        self._neutralise_graph_inputs()
+        try:
+            for bs in reversed(self.graph_bs):
+                self._capture_one(bs, mode="cand")
+            self._cand_capture = "done"
+        except Exception as e:
+            logger.warning("Failed to capture the candidate-sampling graphs (such batches gather their logits): %s", e)
+            self.cand_graphs.clear()
+            self._cand_capture = "no"
+            self._recover_from_failed_capture()
+
     def _recover_from_failed_capture(self) -> None:
         reset_context()
         # a failed capture leaves torch's side capture stream current (torch.cuda.graph.__exit__
@@ -415,7 +481,9 @@ class InferenceExecutor:
         except Exception:  # the invalidated capture reports once more; the device itself is fine
             pass
 
-    def _graph_forward(self, bs: int, greedy: bool = False):
+    def _graph_forward(self, bs: int, greedy: bool = False, mode: str | None = None):
+        mode = mode or ("greedy" if greedy else "gather")
+        greedy = mode == "greedy"
         gv = self.graph_vars
         set_context(False, 0, 0, None, None, gv["slot_mapping"][:bs], gv["context_lens"][:bs],
                     gv["block_tables"][:bs])
@@ -427,6 +495,12 @@ class InferenceExecutor:
             local = hip_ops.sample(out, d[0, :bs], self._dev_samp_i64[:bs], d[1, :bs], d[2, :bs],
                                    seed=self.sampler.seed, offset=0, offset_dev=gv["rng_offset"])
             toks = tp_greedy_tokens(out, local)
+        elif mode == "cand":  # TP > 1, rows greedy or with a small top_k: per-rank top-64 candidates, no logit gather
+            out = gv["logits_local"][:bs]
+            out.copy_(self.model.compute_logits(hidden, gather=False))
+            toks = tp_candidate_tokens(out, lambda cl: hip_ops.sample(
+                cl, d[0, :bs], self._dev_samp_i64[:bs], d[1, :bs], d[2, :bs], seed=self.sampler.seed, offset=0,
+                offset_dev=gv["rng_offset"]))
         else:
             out = gv["logits"][:bs]
             out.copy_(self.model.compute_logits(hidden))
@@ -438,18 +512,19 @@ class InferenceExecutor:
                                gv["slot_mapping"][:bs], gv["context_lens"][:bs], gv["rng_offset"])
 
     @torch.inference_mode()
-    def _capture_one(self, bs: int, greedy: bool = False) -> None:
+    def _capture_one(self, bs: int, greedy: bool = False, mode: str | None = None) -> None:
+        mode = mode or ("greedy" if greedy else "gather")
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):  # warm-up on a side stream (RCCL / hipBLASLt lazy init)
-            self._graph_forward(bs, greedy)
+            self._graph_forward(bs, mode=mode)
         torch.cuda.current_stream(self.device).wait_stream(s)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, pool=self.graph_pool):
-            self._graph_forward(bs, greedy)
+            self._graph_forward(bs, mode=mode)
         if self.graph_pool is None:
             self.graph_pool = graph.pool()
-        (self.greedy_graphs if greedy else self.graphs)[bs] = graph
+        {"greedy": self.greedy_graphs, "cand": self.cand_graphs, "gather": self.graphs}[mode][bs] = graph
         torch.cuda.synchronize(self.device)
         reset_context()
 
@@ -468,8 +543,9 @@ class InferenceExecutor:
         with identical values or that belong to finished sequences."""
         b = inp.num_seqs
         gv = self.graph_vars
-        greedy = bool(self.greedy_graphs) and self._tp_greedy(sequences)
-        graph = self.greedy_graphs[bs] if greedy else self.graphs[bs]
+        mode, family = self._graph_family(sequences)
+        greedy = mode != "gather"          # (this rank's vocab shard is what the step leaves in logits_local)
+        graph = family[bs]
         spec = self._spec
         hit = False
         if spec is not None:
@@ -535,6 +611,7 @@ class InferenceExecutor:
     def cleanup(self) -> None:
         self.graphs.clear()
         self.greedy_graphs.clear()
+        self.cand_graphs.clear()
         self.graph_vars.clear()
         self.graph_pool = None
         self.kv_cache = None

@@ -78,6 +78,9 @@ _SIGNATURES = {
     "mv_greedy_pack": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int,
                                c_void_p]),
     "mv_greedy_merge": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mv_topc_width": (c_int, []),
+    "mv_topc_pack": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mv_topc_unpack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -520,6 +523,29 @@ def greedy_merge(buf, rows: int):
     _check(_lib.mv_greedy_merge(buf.data_ptr(), world, rows, rows_padded, out.data_ptr(), _dt(buf), _stream()),
            "mv_greedy_merge")
     return out
+
+
+TOPC = 64   # == mv_topc_width(): candidates a rank contributes per row
+
+
+def topc_pack(logits_local, rank: int, world: int, rows_padded: int):
+    """-> buf [world, rows_padded, 64, 4] in the logits' dtype (see mv_topc_pack)."""
+    _need_cuda(logits_local)
+    rows, vpr = logits_local.shape
+    buf = torch.empty((world, rows_padded, TOPC, 4), dtype=logits_local.dtype, device=logits_local.device)
+    _check(_lib.mv_topc_pack(logits_local.data_ptr(), logits_local.stride(0), vpr, rank, world, vpr, rows, rows_padded,
+                             buf.data_ptr(), _dt(logits_local), _stream()), "mv_topc_pack")
+    return buf
+
+
+def topc_unpack(buf, rows: int):
+    """-> (cand_logits [rows, world*64] in buf's dtype, cand_idx int32 [rows, world*64] global token ids)."""
+    world, rows_padded = buf.shape[0], buf.shape[1]
+    cl = torch.empty((rows, world * TOPC), dtype=buf.dtype, device=buf.device)
+    ci = torch.empty((rows, world * TOPC), dtype=torch.int32, device=buf.device)
+    _check(_lib.mv_topc_unpack(buf.data_ptr(), world, rows, rows_padded, cl.data_ptr(), ci.data_ptr(), _dt(buf), _stream()),
+           "mv_topc_unpack")
+    return cl, ci
 
 
 # ---------------------------------------------------------------- a2 (device side)

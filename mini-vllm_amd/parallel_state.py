@@ -126,6 +126,24 @@ def tp_greedy_tokens(logits_local: torch.Tensor, local_tokens: torch.Tensor) -> 
     return tp_merge_greedy(local_tokens, vals, vpr)
 
 
+def tp_candidate_tokens(logits_local: torch.Tensor, sample_fn) -> torch.Tensor:
+    """Sampled tokens without the full-logit gather (sampled rows): valid for batches whose rows are
+    greedy or have 1 <= top_k <= hip_ops.TOPC.  Every rank packs the 64 largest logits of its vocab shard per row
+    (+ global indices) into its slot of a zeroed buffer, the all-reduce sums the slots (x + 0: an exact gather,
+    on the peer-to-peer kernel when it is up: no backend collective), ``sample_fn(cand_logits [B, tp*64]) -> int64
+    positions`` runs the ordinary sampler on the candidates — every rank the same Philox stream, so every rank
+    the same token — and the candidate's global index is the token.  512 bytes per row and rank on the wire
+    instead of 2 * V / tp."""
+    from . import hip_ops
+
+    n = logits_local.shape[0]
+    buf = hip_ops.topc_pack(logits_local, _state["rank"], _state["size"], n)
+    tp_all_reduce(buf.view(-1))
+    cand_logits, cand_idx = hip_ops.topc_unpack(buf, n)
+    pos = sample_fn(cand_logits)
+    return cand_idx.gather(1, pos.unsqueeze(1)).squeeze(1).long()
+
+
 def decode_step_is_native(dtype: torch.dtype, hidden_size: int, vocab_size: int) -> bool:
     """True when an all-greedy decode step of a model with these dimensions needs no backend collective: every
     all-reduce and the greedy exchange run on this library's peer-to-peer kernel (-> the step captures into a

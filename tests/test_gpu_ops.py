@@ -411,6 +411,51 @@ def test_sampler_degenerate_rows(H):
     assert toks[1].item() == 7
 
 
+# ------------------------------------------------------------------ f2, sampled rows: per-rank top-64 candidates
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("world,vocab", [(4, 151936), (8, 152064), (2, 320), (8, 320)])
+def test_topc_candidates_hold_the_top_k_set_and_sample_like_the_full_row(H, dtype, world, vocab):
+    """Every rank packs the 64 largest logits of its vocab shard (+ global indices); the slots are summed (here on
+    the host: x + 0, what the all-reduce does) and unpacked.  The candidates must be exactly each shard's top 64
+    by value with the right indices, and the sampler's kept set on the candidates, mapped back, must be the kept
+    set of the full-row sampler for top_k <= 64 (ties at the k-th value may name another, equal-valued token)."""
+    B, vpr = 6, vocab // world
+    g = torch.Generator().manual_seed(vocab + world)
+    full = (torch.randn(B, vocab, generator=g) * 3).to(dtype).to(DEV)
+    bufs = [H.topc_pack(full[:, r * vpr:(r + 1) * vpr], r, world, B) for r in range(world)]
+    assert all(b.shape == (world, B, 64, 4) for b in bufs)
+    summed = torch.stack([b.float() for b in bufs]).sum(0).to(dtype)          # exact: one non-zero term per slot
+    assert torch.equal(summed, torch.stack(bufs).float().sum(0).to(dtype))
+    cl, ci = H.topc_unpack(summed, B)
+    assert cl.shape == (B, world * 64) and ci.dtype == torch.int32
+    real = min(64, vpr)
+    for r in range(world):
+        shard = full[:, r * vpr:(r + 1) * vpr].float()
+        want_vals = shard.topk(real, dim=1).values
+        got_vals, got_idx = cl[:, r * 64:r * 64 + real].float(), ci[:, r * 64:r * 64 + real].long()
+        assert torch.equal(got_vals.sort(dim=1, descending=True).values, want_vals)
+        assert ((got_idx >= r * vpr) & (got_idx < (r + 1) * vpr)).all()
+        assert torch.equal(full.float().gather(1, got_idx), got_vals)            # index <-> value
+        assert (got_idx.sort(dim=1).values.diff(dim=1) > 0).all()                   # no token twice
+        if real < 64:
+            assert torch.isinf(cl[:, r * 64 + real:(r + 1) * 64].float()).all()
+    # the sampler on the candidates == the sampler on the full row (kept sets, then the same set of drawable tokens)
+    temps = torch.tensor([0.7, 1.0, 0.0, 1.3, 0.9, 0.6], device=DEV)
+    ks = torch.tensor([40, 1, -1, 64, 7, 50], dtype=torch.int64, device=DEV)     # row 2 greedy: k irrelevant
+    ps = torch.tensor([0.95, 1.0, 1.0, 0.8, 1.0, 0.5], device=DEV)
+    ms = torch.tensor([0.0, 0.0, 0.0, 0.0, 0.05, 0.0], device=DEV)
+    tok_c, mask_c = H.sample(cl, temps, ks, ps, ms, seed=5, return_mask=True)
+    tok_f, mask_f = H.sample(full, temps, ks, ps, ms, seed=5, return_mask=True)
+    for b in range(B):
+        kept_c = set(ci[b][mask_c[b].bool()].tolist())
+        kept_f = set(mask_f[b].nonzero().flatten().tolist())
+        vals_c = sorted(full[b, sorted(kept_c)].float().tolist())
+        vals_f = sorted(full[b, sorted(kept_f)].float().tolist())
+        assert len(kept_c) == len(kept_f) and vals_c == vals_f, b               # same values; ties may swap tokens
+        assert int(ci[b, tok_c[b]]) in kept_c
+    assert int(ci[2, tok_c[2]]) == int(full[2].float().argmax())                 # the greedy row: the global argmax (no tie here)
+
+
 # ------------------------------------------------------------------ K10
 def _ulp_ok(got, exact, dtype, ulps):
     """|got - exact| <= ulps units in the last place of ``dtype`` at the magnitude of ``exact``

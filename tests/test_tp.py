@@ -459,13 +459,17 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
     kw = dict(max_model_len=512, max_num_batched_tokens=1024, max_num_seqs=8, num_kvcache_blocks=24,
               enforce_eager=True)
 
-    def run(tp, dtype, eager=True, sp=sp):
-        llm = LLM(Config(str(d), dtype=dtype, tensor_parallel_size=tp, seed=3, **{**kw, "enforce_eager": eager}))
+    def run(tp, dtype, eager=True, sp=sp, **over):
+        llm = LLM(Config(str(d), dtype=dtype, tensor_parallel_size=tp, seed=3, **{**kw, "enforce_eager": eager, **over}))
         try:
             ex = llm.model_runner.inference_executor
             from minivllm_amd import parallel_state
 
+            modes = set()
+            real_mode = ex._tp_mode
+            ex._tp_mode = lambda seqs: (modes.add(real_mode(seqs)), real_mode(seqs))[1]
             out = [o_["token_ids"] for o_ in llm.generate(prompts, sp, use_tqdm=False)]
+            run.last = dict(modes=modes, cand_graphs=bool(ex.cand_graphs))
             return out, bool(ex.greedy_graphs), ex.spec_hits, parallel_state.get_custom_all_reduce() is not None
         finally:
             llm.exit()
@@ -490,3 +494,16 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
     if p2p:   # (its own start-up validation decides; test_custom_all_reduce_matches_backend covers the kernel)
         assert captured and spec_hits > 0
     assert not run(2, "float32", eager=False)[1]
+    # sampled rows with a small top_k, 16-bit logits: no logit gather — every rank contributes its 64 best candidates
+    # per row; the ranks draw the same tokens (the driver would otherwise diverge from its worker and
+    # the run would hang or mismatch), the mode really ran, eager and captured replay agree, and every generated
+    # token has a non-zero probability under the same filters on TP = 1 logits is checked by the kernel test
+    small_k = SamplingParams(temperature=0.8, top_p=0.95, top_k=40, max_tokens=12, ignore_eos=True)
+    # (max_num_seqs = the batch: the graph bucket then equals the batch, no padded row changes the split-KV plan, the
+    # logits are bit-identical to eager's and so are the sampled tokens)
+    c_eager = run(2, "bfloat16", sp=small_k, max_num_seqs=len(prompts))[0]
+    assert run.last["modes"] == {"cand"} and [len(t) for t in c_eager] == [12] * len(prompts)
+    c_graph, _, _, p2p = run(2, "bfloat16", eager=False, sp=small_k, max_num_seqs=len(prompts))
+    assert [len(t) for t in c_graph] == [12] * len(prompts)
+    if p2p:
+        assert run.last["cand_graphs"] and c_graph == c_eager

@@ -30,6 +30,8 @@ SHAPES = {
                    ("row", 2048, 6144, False)],
     "qwen2-7b": [("col", 4608, 3584, True), ("row", 3584, 3584, False), ("gated", 18944, 3584, False),
                  ("row", 3584, 18944, False)],
+    "lm-heads": [("col", 151936, 1024, False), ("col", 151936, 2048, False), ("col", 152064, 3584, False),
+                 ("col", 19008, 8192, False)],
     "qwen2-72b-tp8": [("col", 1280, 8192, True), ("row", 8192, 1024, False), ("gated", 3696, 8192, False)],
     "qwen2-72b": [("col", 10240, 8192, True), ("row", 8192, 8192, False), ("gated", 29568, 8192, False),
                   ("row", 8192, 29568, False)],
@@ -76,7 +78,7 @@ def main():
                 print(f"skip {model} {kind} N={n} K={k}: not a mid-M shape", flush=True)
                 continue
             wbytes = n_rows * k * 2
-            copies = max(2, min(48, (400 << 20) // wbytes + 1))
+            copies = max(2, min(48, (400 << 20) // wbytes + 1))   # (>= 2 copies: 1.2 - 2.2 GB for an LM head)
             ws = [(torch.randn(n_rows, k, device=dev) * 0.02).to(torch.bfloat16) for _ in range(copies)]
             wps = [hip_ops.pack_weight(w) for w in ws]
             bias = (torch.randn(n_rows, device=dev) * 0.1).to(torch.bfloat16) if has_bias else None
@@ -99,7 +101,7 @@ def main():
                     bno = bn // 2 if kind == "gated" else bn
                     for sp in ((1, 2, 4) if kind == "row" else (1,)):
                         wgs = -(-m // bm) * -(-n // bno) * sp
-                        if wgs > 640 or wgs < 48 or (k // 64) % sp:
+                        if wgs > (640 if n < 65536 else 4096) or wgs < 48 or (k // 64) % sp:
                             continue
                         if kind == "col":
                             fn = lambda i: hip_ops.linear_mid_m(x, wps[i % copies], n, bias, c)       # noqa: E731
