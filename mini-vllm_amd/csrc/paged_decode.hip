@@ -11,6 +11,15 @@
 // (no cross-lane traffic in the loop besides the in-row DPP dot-product
 // reduction); groups, waves and splits are merged at the end through
 // shuffles, LDS and (only when split) an fp32 workspace.
+//
+// WIDE (n_kv_heads a multiple of TPL = 64 / LPT): the TPL lane groups of a wave take TPL adjacent kv heads of
+// ONE token instead of TPL tokens of one kv head, so a wave-wide load is 1 KiB of contiguous cache (a token
+// row is n_kv_heads x D contiguous elements) instead of TPL pieces of 256 B at a row stride, a workgroup owns
+// (sequence, TPL kv heads, split), and the token -> cache row arithmetic is scalar.  Measured as pure reads
+// (tools/dbg/ingest_probe3.hip): 6.85 TB/s against 6.5 TB/s for the per-head mapping.
+// (The same idea for the matrix-core kernel — a wave per kv head — was measured SLOWER, 94 vs 88 us on Qwen2-7B
+//  heads at B = 256: that kernel is bound by the bytes its 8 resident waves per CU keep in flight, and a wave
+//  that walks twice as many tiles serially keeps no more of them in flight.)
 #include "paged_decode.h"
 #include <cstdlib>
 
@@ -61,31 +70,33 @@ __device__ __forceinline__ float token_sum(float x) {
   return x;
 }
 
-template <typename Tag, int D, int G, int NLOAD, bool UNIFORM>
+template <typename Tag, int D, int G, int NLOAD, bool UNIFORM, bool WIDE>
 __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
   typedef typename elem<Tag>::T T;
   constexpr int VEC = elem<Tag>::VEC;
   constexpr int LPT = D / VEC;       // lanes per token row
-  constexpr int TPL = 64 / LPT;      // tokens per wave-wide load
-  constexpr int TILE = NLOAD * TPL;  // tokens per wave per iteration
+  constexpr int TPL = 64 / LPT;      // tokens (WIDE: kv heads) per wave-wide load
+  constexpr int TILE = WIDE ? NLOAD : NLOAD * TPL;  // tokens per wave per iteration
   constexpr int NW = 4;
   constexpr int UNIT = NW * TILE;
+  constexpr int HG = WIDE ? TPL : 1;  // kv heads per workgroup
   constexpr float NEG_BIG = -1e30f;
 
-  __shared__ float lds_ml[NW][G][2];
-  __shared__ float lds_acc[NW][G][D];
+  __shared__ float lds_ml[NW][HG][G][2];
+  __shared__ float lds_acc[NW][HG][G][D];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int sub = lane % LPT;  // which 16-byte piece of the row
-  const int grp = lane / LPT;  // which token of a wave-wide load
+  const int grp = lane / LPT;  // which token (WIDE: kv head) of a wave-wide load
 
-  const int n_chunks = (p.g_total + G - 1) / G;  // q-head chunks per kv head
-  const int hkv = blockIdx.x / n_chunks;
-  const int chunk = blockIdx.x - hkv * n_chunks;
+  const int n_chunks = WIDE ? 1 : (p.g_total + G - 1) / G;  // q-head chunks per kv head
+  const int hkv0 = WIDE ? blockIdx.x * TPL : blockIdx.x / n_chunks;  // first kv head of this workgroup
+  const int hkv = WIDE ? hkv0 + grp : hkv0;                          // this lane's kv head
+  const int chunk = WIDE ? 0 : blockIdx.x - hkv0 * n_chunks;
   const int split = blockIdx.y;
   const int b = blockIdx.z;
-  const int h0 = hkv * p.g_total + chunk * G;  // first q head of this workgroup
+  const int h0 = hkv * p.g_total + chunk * G;  // first q head of this lane
   const int g_live = min(G, p.g_total - chunk * G);
 
   int ctx = p.context_lens[b];
@@ -120,11 +131,9 @@ __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
   const T *kbase = (const T *)p.k_cache + (int64_t)hkv * D + sub * VEC;
   const T *vbase = (const T *)p.v_cache + (int64_t)hkv * D + sub * VEC;
 
-  for (int u = u_begin; u < u_end; ++u) {
+  // one tile = NLOAD wave-wide loads of K and of V
+  auto load_tile = [&](int u, u32x4 (&kraw)[NLOAD], u32x4 (&vraw)[NLOAD], bool (&valid)[NLOAD]) {
     const int tile_base = (u * NW + wave) * TILE;
-    if (tile_base >= ctx) break;  // wave-uniform
-    u32x4 kraw[NLOAD], vraw[NLOAD];
-    bool valid[NLOAD];
     int64_t uni_row = -1;
     if constexpr (UNIFORM) {  // whole tile inside one KV block
       const int bi = p.bs_shift >= 0 ? (tile_base >> p.bs_shift) : (tile_base / p.block_size);
@@ -136,12 +145,13 @@ __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
     // sequence's token 0 / the tile's first token — finite data, masked to probability 0 below.
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
-      const int tok = tile_base + i * TPL + grp;
+      const int off = WIDE ? i : i * TPL + grp;  // token of this lane within the tile
+      const int tok = tile_base + off;
       int64_t row;
       bool ok = tok < ctx;
       if constexpr (UNIFORM) {
         ok = ok && uni_row >= 0;
-        row = (uni_row >= 0 ? uni_row : 0) + (ok ? i * TPL + grp : 0);
+        row = (uni_row >= 0 ? uni_row : 0) + (ok ? off : 0);
       } else {
         const int tk = ok ? tok : tile_base;  // tile_base < ctx
         const int bi = p.bs_shift >= 0 ? (tk >> p.bs_shift) : (tk / p.block_size);
@@ -155,9 +165,10 @@ __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
       // non-temporal loads keep them from evicting the weights / activations that do get re-used
       kraw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(kbase + row * row_stride));
       vraw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(vbase + row * row_stride));
-      if (!ok) vraw[i] = u32x4{0u, 0u, 0u, 0u};  // row 0 of a foreign block may hold anything (0 * NaN)
     }
+  };
 
+  auto consume_tile = [&](const u32x4 (&kraw)[NLOAD], const u32x4 (&vraw)[NLOAD], const bool (&valid)[NLOAD]) {
     // scores (log2 domain) + online softmax, per query head
     float pr[G][NLOAD];
 #pragma unroll
@@ -187,14 +198,38 @@ __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       float vf[VEC];
-      unpack_vec<Tag>(vraw[i], vf);
+      // row 0 of a foreign block may hold anything (0 * NaN)
+      unpack_vec<Tag>(valid[i] ? vraw[i] : u32x4{0u, 0u, 0u, 0u}, vf);
 #pragma unroll
       for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[g][j] = fmaf(pr[g][i], vf[j], acc[g][j]);
     }
+  };
+
+  // a tile at or past the context is skipped whole (wave-uniform)
+  auto live = [&](int u) { return u < u_end && (u * NW + wave) * TILE < ctx; };
+  // (round 2: a second register set with the next tile's loads in flight during the arithmetic — 256 VGPRs,
+  //  2 waves per SIMD — measured no faster than this loop, 166 vs 165 us: the HBM side is the limit)
+  for (int u = u_begin; live(u); ++u) {
+    u32x4 kraw[NLOAD], vraw[NLOAD];
+    bool valid[NLOAD];
+    load_tile(u, kraw, vraw, valid);
+    consume_tile(kraw, vraw, valid);
   }
 
+  if constexpr (WIDE) {
+    // lane groups hold different kv heads: nothing to merge inside the wave
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (sub == 0) {
+        lds_ml[wave][grp][g][0] = m[g];
+        lds_ml[wave][grp][g][1] = l[g];
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) lds_acc[wave][grp][g][sub * VEC + j] = acc[g][j];
+    }
+  } else {
   // merge the TPL lane groups of this wave
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -211,30 +246,31 @@ __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
     }
     if (grp == 0) {
       if (sub == 0) {
-        lds_ml[wave][g][0] = mm;
-        lds_ml[wave][g][1] = ll;
+        lds_ml[wave][0][g][0] = mm;
+        lds_ml[wave][0][g][1] = ll;
       }
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) lds_acc[wave][g][sub * VEC + j] = acc[g][j];
+      for (int j = 0; j < VEC; ++j) lds_acc[wave][0][g][sub * VEC + j] = acc[g][j];
     }
+  }
   }
   __syncthreads();
 
   // merge the 4 waves; write the output row or this split's partial
-  for (int idx = threadIdx.x; idx < G * D; idx += blockDim.x) {
-    const int g = idx / D, d = idx - g * D;
+  for (int idx = threadIdx.x; idx < HG * G * D; idx += blockDim.x) {
+    const int hg = idx / (G * D), g = (idx / D) % G, d = idx % D;
     if (g >= g_live) continue;
-    float M = lds_ml[0][g][0];
+    float M = lds_ml[0][hg][g][0];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) M = fmaxf(M, lds_ml[w][g][0]);
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, lds_ml[w][hg][g][0]);
     float L = 0.f, A = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      const float f = __builtin_amdgcn_exp2f(lds_ml[w][g][0] - M);
-      L += lds_ml[w][g][1] * f;
-      A += lds_acc[w][g][d] * f;
+      const float f = __builtin_amdgcn_exp2f(lds_ml[w][hg][g][0] - M);
+      L += lds_ml[w][hg][g][1] * f;
+      A += lds_acc[w][hg][g][d] * f;
     }
-    const int h = h0 + g;
+    const int h = (hkv0 + hg) * p.g_total + chunk * G + g;
     if (p.nsplit == 1) {
       const float o = L > 0.f ? A / L : 0.f;
       ((T *)p.out)[((int64_t)b * p.n_heads + h) * D + d] = elem<Tag>::st(o);
@@ -301,6 +337,7 @@ struct DecodePlan {
   int nsplit;
   bool uniform;
   bool mfma;  // tensor-core variant (paged_decode_mfma.hip)
+  bool wide;  // vector kernel, TPL adjacent kv heads per workgroup (whole-row loads)
 };
 
 constexpr int kTargetWorkgroups = 2048;  // ~8 workgroups per CU
@@ -320,6 +357,8 @@ bool make_plan(int batch, int n_heads, int n_kv_heads, int head_dim, int block_s
   if (n_kv_heads <= 0 || n_heads % n_kv_heads) return false;
   if (head_dim != 64 && head_dim != 128) return false;
   const int g_total = n_heads / n_kv_heads;
+  int kv_groups = n_kv_heads;  // workgroups along the kv-head axis
+  pl->wide = false;
   // >= 4 query heads per kv head: QK^T and PV go to the matrix cores (the vector path spends
   // ~G x 20 VALU instructions per key and drops to 2-3.7 TB/s at G = 7..8)
   const int min_group = (flags & MV_DECODE_VECTOR) ? 1 << 30 : ((flags & MV_DECODE_MFMA) ? 1 : kMfmaMinGroup);
@@ -337,15 +376,20 @@ bool make_plan(int batch, int n_heads, int n_kv_heads, int head_dim, int block_s
     const int vec = dtype == MV_F32 ? 4 : 8;
     const int tpl = 64 / (head_dim / vec);
     pl->nload = pl->g_chunk <= 4 ? 8 : 4;
-    pl->tile = pl->nload * tpl;
+    pl->wide = pl->n_chunks == 1 && pl->g_chunk <= 4 && n_kv_heads % tpl == 0 && !(flags & MV_DECODE_PER_HEAD);
+    pl->tile = pl->wide ? pl->nload : pl->nload * tpl;
     pl->unit = 4 * pl->tile;
     pl->uniform = block_size % pl->tile == 0;
+    if (pl->wide) kv_groups = n_kv_heads / tpl;
   }
   const int64_t max_ctx = (int64_t)max_blocks * block_size;
   const int max_units = (int)((max_ctx + pl->unit - 1) / pl->unit);
-  const int64_t wg = (int64_t)batch * n_kv_heads * pl->n_chunks;
+  const int64_t wg = (int64_t)batch * kv_groups * pl->n_chunks;
   // the matrix-core kernel keeps 4 workgroups per CU resident (LDS): one wave of 1024 is enough
-  const int target = pl->mfma ? kTargetWorkgroups / 2 : kTargetWorkgroups;
+  // whole-row loads: HBM likes FEWER concurrent streams (B = 256 x 1024 tokens: 162 us at 512 workgroups,
+  // 170 us at 1024, 182 us at 2560; the per-head mapping: 171 us at its best)
+  int target = pl->wide ? kTargetWorkgroups / 4 : (pl->mfma ? kTargetWorkgroups / 2 : kTargetWorkgroups);
+  if ((flags >> 8) & 0xff) target = ((flags >> 8) & 0xff) * 64;  // tuning aid: bits 8-15 = target workgroups / 64
   int ns = wg > 0 ? (int)((target + wg - 1) / wg) : 1;
   if (ns > max_units) ns = max_units;
   if (ns > kMaxSplits) ns = kMaxSplits;
@@ -358,11 +402,22 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 template <typename Tag, int D, int G, int NLOAD>
 void launch_g(const DecodeParams &p, const DecodePlan &pl, int batch, hipStream_t stream) {
-  dim3 grid(p.n_kv_heads * pl.n_chunks, pl.nsplit, batch), block(256);
+  dim3 block(256);
+  if constexpr (G <= 4) {
+    if (pl.wide) {
+      dim3 grid(p.n_kv_heads / (64 / (D / elem<Tag>::VEC)), pl.nsplit, batch);
+      if (pl.uniform)
+        hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, true, true>), grid, block, 0, stream, p);
+      else
+        hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, false, true>), grid, block, 0, stream, p);
+      return;
+    }
+  }
+  dim3 grid(p.n_kv_heads * pl.n_chunks, pl.nsplit, batch);
   if (pl.uniform)
-    hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, true>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, true, false>), grid, block, 0, stream, p);
   else
-    hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, false, false>), grid, block, 0, stream, p);
 }
 
 template <typename Tag, int D>

@@ -91,13 +91,15 @@ class MvHipError(RuntimeError):
 
 # ---------------------------------------------------------------- tuning switches
 # The C-ABI reads no environment: the overrides below are read HERE, once, and passed as explicit arguments.
-MV_DECODE_VECTOR, MV_DECODE_MFMA, MV_DECODE_KLDS_OFF, MV_DECODE_KLDS_ON = 1, 2, 4, 8
+MV_DECODE_VECTOR, MV_DECODE_MFMA, MV_DECODE_KLDS_OFF, MV_DECODE_KLDS_ON, MV_DECODE_PER_HEAD = 1, 2, 4, 8, 16
 MV_PREFILL_SIMPLE = 1
 
 
 def _decode_flags_from_env() -> int:
     """MV_DECODE_MFMA_MIN_G=1 / 99: matrix-core decode kernel always / never; MV_DECODE_MFMA_KLDS=0 / 1: K straight
-    to registers / through LDS.  (Bench and debugging aids; unset = the kernels choose from the shape.)"""
+    to registers / through LDS; MV_DECODE_PER_HEAD=1: vector kernel with one kv head per workgroup;
+    MV_DECODE_TARGET_WGS=n: workgroups the context split aims for (multiple of 64).
+    (Bench and debugging aids; unset = the kernels choose from the shape.)"""
     f = 0
     g = os.environ.get("MV_DECODE_MFMA_MIN_G")
     if g is not None:
@@ -105,6 +107,11 @@ def _decode_flags_from_env() -> int:
     k = os.environ.get("MV_DECODE_MFMA_KLDS")
     if k is not None:
         f |= MV_DECODE_KLDS_ON if int(k) else MV_DECODE_KLDS_OFF
+    if os.environ.get("MV_DECODE_PER_HEAD") == "1":
+        f |= MV_DECODE_PER_HEAD
+    t = os.environ.get("MV_DECODE_TARGET_WGS")
+    if t is not None:
+        f |= (max(1, min(255, int(t) // 64))) << 8
     return f
 
 

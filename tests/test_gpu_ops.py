@@ -98,6 +98,9 @@ DECODE_CASES = [
     (3, 16, 4, 128, 64, [31, 32, 33]),          # G = 4: smallest matrix-core group, tile edges
     (2, 40, 2, 128, 64, [500, 129]),            # G = 20: two head chunks, ragged second chunk
     (2, 28, 4, 128, 32, [100, 2000]),           # G = 7 with 32-token blocks, split-KV
+    (3, 16, 8, 64, 4, [1, 9, 40]),              # whole-row mapping (8 kv heads of D = 64 per load), generic path
+    (2, 24, 8, 128, 64, [70, 300]),             # whole-row mapping, G = 3
+    (2, 8, 8, 128, 12, [5, 100]),               # whole-row mapping, MHA, block size not a multiple of the tile
 ]
 
 
@@ -113,6 +116,27 @@ def test_paged_decode_vs_oracle(H, case, dtype):
     out = H.paged_decode(q.to(DEV), kc.to(DEV), vc.to(DEV), table.to(DEV), ctx.to(DEV), scale)
     assert out.dtype == dtype and out.shape == (B, Hq, D)
     torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
+
+
+def test_paged_decode_whole_row_and_per_head_mappings_agree(H):
+    """mv_paged_decode picks the whole-row mapping (a workgroup owns 4 adjacent kv heads) when the head layout
+    allows; MV_DECODE_PER_HEAD forces the one-kv-head-per-workgroup mapping.  Same numbers up to the order the
+    partial softmax states are merged in, and both within the oracle's tolerance."""
+    dtype = torch.bfloat16
+    B, Hq, Hkv, D, bs = 6, 16, 8, 128, 64
+    ctxs = [1, 63, 64, 65, 700, 2049]
+    kc, vc, table = _make_paged(B, Hkv, D, bs, ctxs, dtype, seed=21)
+    table[4, 3] = -1                       # a hole in the table contributes nothing (DESIGN Q9)
+    q = _randn(B, Hq, D, dtype=dtype, seed=22)
+    ctx = torch.tensor(ctxs, dtype=torch.int32)
+    scale = D ** -0.5
+    ref = O.paged_decode(q, kc, vc, table, ctx, scale)
+    args = (q.to(DEV), kc.to(DEV), vc.to(DEV), table.to(DEV), ctx.to(DEV), scale)
+    wide = H.paged_decode(*args, flags=0)
+    per_head = H.paged_decode(*args, flags=H.MV_DECODE_PER_HEAD)
+    torch.testing.assert_close(wide.float().cpu(), ref, **_tol(dtype))
+    torch.testing.assert_close(per_head.float().cpu(), ref, **_tol(dtype))
+    torch.testing.assert_close(wide.float(), per_head.float(), rtol=2 ** -7, atol=2e-3)
 
 
 def test_paged_decode_edge_cases(H):

@@ -81,11 +81,14 @@ if __name__ == "__main__":
             bench_decode(256, 16, 8, 128, 1024)
         print("--- (warm-up above) ---")
         for rep in range(3):
-            for fl in (0,):   # (round 2: an XCD-aware grid order, flag 16, was tried here: 172 -> 173 us, dropped)
+            # flag 16 = one kv head per workgroup (the round-1 mapping); bits 8-15 = context-split target / 64
+            # (round 2: an XCD-aware grid order was tried here: 172 -> 173 us, dropped)
+            for fl in (16, 0):
                 bench_decode(256, 16, 8, 128, 1024, flags=fl)
-                bench_decode(256, 28, 4, 128, 1024, flags=fl)
-                bench_decode(256, 8, 1, 128, 1024, flags=fl)
                 bench_decode(64, 16, 8, 128, 4096, layers=2, flags=fl)
+                bench_decode(8, 16, 8, 128, 4096, layers=2, flags=fl)
+            bench_decode(256, 28, 4, 128, 1024, flags=0)
+            bench_decode(256, 8, 1, 128, 1024, flags=0)
         raise SystemExit(0)
     if a.prefill_only:
         # the chip's clock ramps over the first second of load: warm up, then interleave the variants and repeat
