@@ -205,6 +205,16 @@ int mv_gate_up_silu_small_m(const void *x, int64_t x_stride, const void *w_gate_
                             void *out, int64_t out_stride, int m, int n_inter,
                             int k, int dtype, int shape, void *stream);
 
+/* K10 on the fragment-ordered weight copy of mv_pack_weight (below): the same two operations, the same summation
+ * order and rounding points (results bit-identical to the row-major entry points); only the weight address stream
+ * differs — 1 KiB contiguous per wave-wide load instead of 16 pieces of 64 B.  The gated form needs n_inter % 16 == 0. */
+int mv_linear_small_m_packed(const void *x, int64_t x_stride, const void *w_packed,
+                             const void *bias, void *out, int64_t out_stride, int m,
+                             int n, int k, int dtype, int shape, void *stream);
+int mv_gate_up_silu_small_m_packed(const void *x, int64_t x_stride, const void *w_gate_up_packed,
+                                   void *out, int64_t out_stride, int m, int n_inter,
+                                   int k, int dtype, int shape, void *stream);
+
 /* K11 — decode-batch linear layer for 17..512 rows (the headline batch, max_num_seqs = 256): same contract as
  * mv_linear_small_m (fp32 accumulation, bias in fp32, one rounding) with K % 64 == 0, N % 4 == 0.  Replaces the
  * F.linear calls of minivllm/models/layers/linear.py:130,163,316 where the library GEMM is bound by how fast a CU

@@ -49,7 +49,10 @@ __host__ __device__ constexpr int unroll_of(int rpw, int mt) { return rpw + mt <
 // ds_read_b128 -- instead of 16 rows x 64 B per load instruction straight into the B-operand registers, which
 // costs the texture path as much as the weight fragments do.  Chosen by run() where it measured faster.
 // WLDS: the same for the weight block of a wave that owns one 16-row tile (x then stays in registers).
-template <typename Tag, int RPW, int MT, bool GATED, bool XLDS, bool WLDS = false>
+// PACKED: W is the fragment-ordered copy mv_pack_weight makes for the decode-batch kernel ([N/16][K/32][64 lanes][8]:
+// the A fragment of a (16-row tile, k step) is 1 KiB of contiguous memory and a wave's K slice of a tile one
+// contiguous run), read non-temporally: every load instruction is a whole-line burst instead of 16 pieces of 64 B.
+template <typename Tag, int RPW, int MT, bool GATED, bool XLDS, bool WLDS = false, bool PACKED = false>
 __global__ void __launch_bounds__((GATED ? 2 : 1) * RPW * MT >= 12 ? 512 : 1024)
 linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of partial-tile LDS allow <= 5 waves)
   typedef uint16_t T;
@@ -60,15 +63,33 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
   constexpr int NA = GATED ? 2 * RPW : RPW;  // weight tiles per wave
   constexpr int kUnroll = unroll_of(NA, MT);
   const int steps = p.K >> 5;
-  const int s_lo = (int)((int64_t)steps * wave / nwaves), s_hi = (int)((int64_t)steps * (wave + 1) / nwaves);
+  int s_lo, s_hi;
+  if constexpr (PACKED) {
+    // K slices in whole blocks of kUnroll steps: no wave but the last re-reads part of a block
+    const int nblk = (steps + kUnroll - 1) / kUnroll;
+    s_lo = (int)((int64_t)nblk * wave / nwaves) * kUnroll;
+    s_hi = min(steps, (int)((int64_t)nblk * (wave + 1) / nwaves) * kUnroll);
+  } else {
+    s_lo = (int)((int64_t)steps * wave / nwaves);
+    s_hi = (int)((int64_t)steps * (wave + 1) / nwaves);
+  }
 
+  static_assert(!(PACKED && WLDS), "packed weights go straight to registers");
+  constexpr int WSTEP = PACKED ? 512 : 32;  // elements between the fragments of consecutive k steps
   const T *wp[NA];
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
-    int n = n0 + (a % RPW) * 16 + r16;
-    n = n < p.N ? n : p.N - 1;  // ragged last tile: re-read the last row, dropped at the store
-    if (GATED && a >= RPW) n += p.N;
-    wp[a] = (const T *)p.w + (int64_t)n * p.K + g * 8;
+    if constexpr (PACKED) {
+      // tile index: the packed copy pads N up to whole tiles (zero rows), GATED: the up rows start at tile N / 16
+      const int t = blockIdx.x * RPW + (a % RPW) + (GATED && a >= RPW ? p.N >> 4 : 0);
+      const int t_last = ((GATED ? 2 * p.N : p.N) + 15) / 16 - 1;
+      wp[a] = (const T *)p.w + (int64_t)(t < t_last ? t : t_last) * steps * 512 + lane * 8;
+    } else {
+      int n = n0 + (a % RPW) * 16 + r16;
+      n = n < p.N ? n : p.N - 1;  // ragged last tile: re-read the last row, dropped at the store
+      if (GATED && a >= RPW) n += p.N;
+      wp[a] = (const T *)p.w + (int64_t)n * p.K + g * 8;
+    }
   }
   const T *xp[MT];
 #pragma unroll
@@ -116,7 +137,12 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
     for (int u = 0; u < kUnroll; ++u) {
       if constexpr (!WLDS) {
 #pragma unroll
-        for (int a = 0; a < NA; ++a) wf[u][a] = *(const u32x4 *)(wp[a] + sb * 32 + u * 32);
+        for (int a = 0; a < NA; ++a) {
+          if constexpr (PACKED)
+            wf[u][a] = __builtin_nontemporal_load((const u32x4 *)(wp[a] + (int64_t)(sb + u) * WSTEP));
+          else
+            wf[u][a] = *(const u32x4 *)(wp[a] + sb * 32 + u * 32);
+        }
       }
       if constexpr (!XLDS) {
 #pragma unroll
@@ -215,24 +241,24 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
   }
 }
 
-template <typename Tag, int RPW, bool GATED, bool XLDS>
+template <typename Tag, int RPW, bool GATED, bool XLDS, bool PACKED>
 int launch_mt_(const LinearParams &p, int mt, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
   switch (mt) {
-    case 1: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 1, GATED, XLDS>), grid, block, lds, stream, p); break;
-    case 2: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 2, GATED, XLDS>), grid, block, lds, stream, p); break;
-    case 3: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 3, GATED, XLDS>), grid, block, lds, stream, p); break;
-    default: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 4, GATED, XLDS>), grid, block, lds, stream, p); break;
+    case 1: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 1, GATED, XLDS, false, PACKED>), grid, block, lds, stream, p); break;
+    case 2: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 2, GATED, XLDS, false, PACKED>), grid, block, lds, stream, p); break;
+    case 3: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 3, GATED, XLDS, false, PACKED>), grid, block, lds, stream, p); break;
+    default: hipLaunchKernelGGL((linear_small_m_kernel<Tag, RPW, 4, GATED, XLDS, false, PACKED>), grid, block, lds, stream, p); break;
   }
   MV_LAUNCH_CHECK();
   return MV_OK;
 }
 
-template <typename Tag, bool GATED, bool XLDS>
+template <typename Tag, bool GATED, bool XLDS, bool PACKED>
 int launch(const LinearParams &p, int rpw, int mt, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
   if constexpr (!GATED)
-    if (rpw == 4) return launch_mt_<Tag, 4, GATED, XLDS>(p, mt, grid, block, lds, stream);
-  if (rpw == 2) return launch_mt_<Tag, 2, GATED, XLDS>(p, mt, grid, block, lds, stream);
-  return launch_mt_<Tag, 1, GATED, XLDS>(p, mt, grid, block, lds, stream);
+    if (rpw == 4) return launch_mt_<Tag, 4, GATED, XLDS, PACKED>(p, mt, grid, block, lds, stream);
+  if (rpw == 2) return launch_mt_<Tag, 2, GATED, XLDS, PACKED>(p, mt, grid, block, lds, stream);
+  return launch_mt_<Tag, 1, GATED, XLDS, PACKED>(p, mt, grid, block, lds, stream);
 }
 
 // `shape` (the last-but-one argument of the entry points) overrides the launch shape, for tools/bench_linear.py
@@ -245,10 +271,13 @@ int launch(const LinearParams &p, int rpw, int mt, dim3 grid, dim3 block, size_t
 // take 2-4 row tiles per wave.  K slices per workgroup: enough waves that the chip holds >= ~2048 of
 // them, each slice at least one full block of k-steps (two for the last doubling).  Measured choices:
 // tools/bench_linear.py --sweep.
-template <bool GATED>
+template <bool GATED, bool PACKED = false>
 int run(const LinearParams &p, int dtype, int shape, hipStream_t st) {
   const int m = p.M, n = p.N, mt = (m + 15) / 16, steps = p.K / 32;
   int rpw = GATED ? (m > 2 && n >= 16384 ? 2 : 1) : (m <= 2 ? 1 : (n >= 65536 ? 4 : (n >= 8192 ? 2 : 1)));
+  // (on the packed copy 4 row tiles per wave never measured fastest, nor 2 + 2 tiles for the gated form:
+  //  Qwen2-7B gate_up at 16 rows 44 us with 1 + 1 tiles over 7 waves, 64 us with 2 + 2)
+  if (PACKED) rpw = GATED ? 1 : (n > 4096 ? 2 : 1);
   const int force_rpw = shape & 15;
   if (force_rpw == 1 || force_rpw == 2 || (force_rpw == 4 && !GATED)) rpw = force_rpw;
   const int na = GATED ? 2 * rpw : rpw;
@@ -258,6 +287,21 @@ int run(const LinearParams &p, int dtype, int shape, hipStream_t st) {
   while (waves < 16 && tiles * waves < 2048 && waves * 2 * na * mt <= 64 &&
          steps / (waves * 2) >= (waves == 8 ? 2 * unroll : unroll))
     waves *= 2;
+  if (PACKED) {
+    // whole-line weight loads (tools/bench_linear.py --packed, M = 1 and 8): what matters is that every wave of the
+    // workgroup walks the same number of whole K blocks — the largest wave count in 6..16 that divides them, 7
+    // where none does (Qwen2-7B, K = 3584: 7 / 14 waves 8.3 us for the qkv matrix, 8 waves 9.1, 16 waves 9.0)
+    const int nblk = (steps + unroll - 1) / unroll;
+    // (the gated form carries two tiles per wave: 6..8 waves; 14-16 measured 1-15 % slower at 8-16 rows)
+    waves = 7;
+    for (int w = GATED ? 8 : 16; w >= 6; --w)
+      if (nblk % w == 0) {
+        waves = w;
+        break;
+      }
+    if (waves > nblk) waves = nblk;
+    while (waves > 1 && waves * na * mt > 64) --waves;
+  }
   const int force_waves = (shape >> 4) & 31;
   if (force_waves >= 1 && force_waves <= 16 && force_waves * na * mt <= 64) waves = force_waves;
   while (waves > 1 && waves * na * mt > 64) waves /= 2;  // 64 KB of LDS for the partial tiles
@@ -275,7 +319,7 @@ int run(const LinearParams &p, int dtype, int shape, hipStream_t st) {
   // weight block also comes in by whole-row DMA (+13..25 % on the down / Qwen2-7B qkv projections at M <= 8,
   // -5 % on single-block slices and on the LM head, tools/dbg/wlds_bench.sh); MV_LINEAR_WLDS=1/-1 forces
   const int force_wlds = ((shape >> 11) & 3) == 1 ? 1 : (((shape >> 11) & 3) == 2 ? -1 : 0);
-  const bool wlds = force_wlds ? force_wlds > 0 : (steps / waves > unroll && n < 65536);
+  const bool wlds = !PACKED && (force_wlds ? force_wlds > 0 : (steps / waves > unroll && n < 65536));
   if (wlds && !xlds && mt == 1 && na <= 2) {
     const size_t wblock = (size_t)na * 16 * unroll * 64;
     while (waves > 1 && waves * wblock > 65536) waves /= 2;
@@ -302,10 +346,10 @@ int run(const LinearParams &p, int dtype, int shape, hipStream_t st) {
 #undef MV_WLDS
   }
   if (xlds)
-    return dtype == MV_BF16 ? launch<bf16_tag, GATED, true>(p, rpw, mt, grid, block, lds, st)
-                            : launch<f16_tag, GATED, true>(p, rpw, mt, grid, block, lds, st);
-  return dtype == MV_BF16 ? launch<bf16_tag, GATED, false>(p, rpw, mt, grid, block, lds, st)
-                          : launch<f16_tag, GATED, false>(p, rpw, mt, grid, block, lds, st);
+    return dtype == MV_BF16 ? launch<bf16_tag, GATED, true, PACKED>(p, rpw, mt, grid, block, lds, st)
+                            : launch<f16_tag, GATED, true, PACKED>(p, rpw, mt, grid, block, lds, st);
+  return dtype == MV_BF16 ? launch<bf16_tag, GATED, false, PACKED>(p, rpw, mt, grid, block, lds, st)
+                          : launch<f16_tag, GATED, false, PACKED>(p, rpw, mt, grid, block, lds, st);
 }
 
 int check(const void *x, int64_t x_stride, const void *w, const void *bias, void *out, int64_t out_stride, int m,
@@ -336,4 +380,25 @@ extern "C" int mv_gate_up_silu_small_m(const void *x, int64_t x_stride, const vo
   if (int e = check(x, x_stride, w_gate_up, nullptr, out, out_stride, m, n_inter, k, dtype)) return e;
   LinearParams p{x, w_gate_up, nullptr, out, x_stride, out_stride, m, n_inter, k};
   return run<true>(p, dtype, shape, (hipStream_t)stream);
+}
+
+// The same two entry points on the fragment-ordered weight copy of mv_pack_weight (include/mvhip.h): same
+// arithmetic, same summation order and rounding points — only where the weight bytes come from differs.
+extern "C" int mv_linear_small_m_packed(const void *x, int64_t x_stride, const void *w_packed, const void *bias,
+                                        void *out, int64_t out_stride, int m, int n, int k, int dtype, int shape,
+                                        void *stream) {
+  if (m == 0 || n == 0) return MV_OK;
+  if (int e = check(x, x_stride, w_packed, bias, out, out_stride, m, n, k, dtype)) return e;
+  LinearParams p{x, w_packed, bias, out, x_stride, out_stride, m, n, k};
+  return run<false, true>(p, dtype, shape, (hipStream_t)stream);
+}
+
+extern "C" int mv_gate_up_silu_small_m_packed(const void *x, int64_t x_stride, const void *w_gate_up_packed,
+                                              void *out, int64_t out_stride, int m, int n_inter, int k, int dtype,
+                                              int shape, void *stream) {
+  if (m == 0 || n_inter == 0) return MV_OK;
+  if (n_inter & 15) return MV_E_SHAPE;  // the up rows must start on a tile boundary of the packed copy
+  if (int e = check(x, x_stride, w_gate_up_packed, nullptr, out, out_stride, m, n_inter, k, dtype)) return e;
+  LinearParams p{x, w_gate_up_packed, nullptr, out, x_stride, out_stride, m, n_inter, k};
+  return run<true, true>(p, dtype, shape, (hipStream_t)stream);
 }

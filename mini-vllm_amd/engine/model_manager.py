@@ -98,9 +98,9 @@ class ModelManager:
         # params already have `dtype`; this also casts the RoPE tables like the reference's
         # model.to(device, dtype) does (its bf16 runs rotate with bf16-rounded cos/sin)
         self.model = model.to(device=self.device, dtype=dtype)
-        # decode batches of 17..512 rows stream a fragment-ordered copy of every projection weight
+        # decode steps stream a fragment-ordered copy of every projection weight and of the LM head
         # (layers/linear.py); MV_PACK_WEIGHTS=0 keeps only the row-major weights (library GEMMs above 16-32 rows)
-        if os.environ.get("MV_PACK_WEIGHTS", "1") != "0" and cfg.max_num_seqs > 16:
+        if os.environ.get("MV_PACK_WEIGHTS", "1") != "0":
             for mod in self.model.modules():
                 if hasattr(mod, "pack_for_decode"):
                     mod.pack_for_decode()

@@ -123,7 +123,8 @@ class QwenMLP(nn.Module):
         w, gu = self.gate_up_proj.weight, self.gate_up_proj
         flat = x.dim() == 2
         if small_m(x, w):  # decode-sized batch: SiluAndMul in the epilogue of the weight-streaming gate_up kernel
-            return self.down_proj(hip_ops.gate_up_silu_small_m(x, w), reduce=reduce, partial_ok=flat)
+            return self.down_proj(hip_ops.gate_up_silu_small_m(x, w, packed=gu.weight_packed), reduce=reduce,
+                                  partial_ok=flat)
         n_inter = w.shape[0] // 2
         if mid_m(x, gu.weight_packed) and n_inter % 16 == 0 and hip_ops.linear_mid_m_ok(x, n_inter):
             cfg, _ = mid_plan("gated", x.numel() // x.shape[-1], n_inter, w.shape[1])

@@ -53,6 +53,10 @@ _SIGNATURES = {
                                   c_int, c_int, c_int, c_void_p]),
     "mv_gate_up_silu_small_m": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                         c_int, c_int, c_void_p]),
+    "mv_linear_small_m_packed": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                         c_int, c_int, c_int, c_void_p]),
+    "mv_gate_up_silu_small_m_packed": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                               c_int, c_int, c_void_p]),
     "mv_packed_weight_elems": (c_size_t, [c_int, c_int]),
     "mv_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mv_linear_mid_m": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
@@ -424,8 +428,14 @@ def small_m_shape(rpw: int = 0, waves: int = 0, xlds: int = 0, wlds: int = 0) ->
     return (rpw & 15) | ((waves & 31) << 4) | (({0: 0, 1: 1, -1: 2}[xlds]) << 9) | (({0: 0, 1: 1, -1: 2}[wlds]) << 11)
 
 
-def linear_small_m(x, weight, bias=None, shape: int = 0):
-    """x [..., K] (<= 64 rows), weight [N, K], bias [N] | None -> [..., N]; fp32 accumulation."""
+def _packed_ok(packed, n_rows: int, k: int, dtype) -> bool:
+    return (packed is not None and packed.dtype == dtype and packed.is_contiguous()
+            and packed.numel() == -(-n_rows // 16) * 16 * k)
+
+
+def linear_small_m(x, weight, bias=None, shape: int = 0, packed=None):
+    """x [..., K] (<= 64 rows), weight [N, K], bias [N] | None -> [..., N]; fp32 accumulation.  ``packed``: the
+    fragment-ordered copy of ``weight`` (pack_weight) — same result, streamed in whole lines."""
     _need_cuda(x, weight)
     x2, k = _rows2d(x)
     n = weight.shape[0]
@@ -434,12 +444,18 @@ def linear_small_m(x, weight, bias=None, shape: int = 0):
     if bias is not None and (bias.dtype != x.dtype or bias.shape[0] != n):
         raise ValueError("bias dtype/shape mismatch")
     out = torch.empty((x2.shape[0], n), dtype=x.dtype, device=x.device)
-    _check(_lib.mv_linear_small_m(x2.data_ptr(), x2.stride(0), weight.data_ptr(), _ptr(bias), out.data_ptr(),
-                                  out.stride(0), x2.shape[0], n, k, _dt(x), int(shape), _stream()), "mv_linear_small_m")
+    if _packed_ok(packed, n, k, x.dtype):
+        _check(_lib.mv_linear_small_m_packed(x2.data_ptr(), x2.stride(0), packed.data_ptr(), _ptr(bias),
+                                             out.data_ptr(), out.stride(0), x2.shape[0], n, k, _dt(x), int(shape),
+                                             _stream()), "mv_linear_small_m_packed")
+    else:
+        _check(_lib.mv_linear_small_m(x2.data_ptr(), x2.stride(0), weight.data_ptr(), _ptr(bias), out.data_ptr(),
+                                      out.stride(0), x2.shape[0], n, k, _dt(x), int(shape), _stream()),
+               "mv_linear_small_m")
     return out.view(*x.shape[:-1], n)
 
 
-def gate_up_silu_small_m(x, weight, shape: int = 0):
+def gate_up_silu_small_m(x, weight, shape: int = 0, packed=None):
     """x [..., K] (<= 64 rows), weight [2I, K] = [gate rows ; up rows] -> silu(x Wg^T) * (x Wu^T), [..., I]."""
     _need_cuda(x, weight)
     x2, k = _rows2d(x)
@@ -447,9 +463,14 @@ def gate_up_silu_small_m(x, weight, shape: int = 0):
         raise ValueError(f"weight {tuple(weight.shape)} is not a merged [2I, {k}] gate_up matrix")
     n = weight.shape[0] // 2
     out = torch.empty((x2.shape[0], n), dtype=x.dtype, device=x.device)
-    _check(_lib.mv_gate_up_silu_small_m(x2.data_ptr(), x2.stride(0), weight.data_ptr(), out.data_ptr(),
-                                        out.stride(0), x2.shape[0], n, k, _dt(x), int(shape), _stream()),
-           "mv_gate_up_silu_small_m")
+    if n % 16 == 0 and _packed_ok(packed, 2 * n, k, x.dtype):
+        _check(_lib.mv_gate_up_silu_small_m_packed(x2.data_ptr(), x2.stride(0), packed.data_ptr(), out.data_ptr(),
+                                                   out.stride(0), x2.shape[0], n, k, _dt(x), int(shape), _stream()),
+               "mv_gate_up_silu_small_m_packed")
+    else:
+        _check(_lib.mv_gate_up_silu_small_m(x2.data_ptr(), x2.stride(0), weight.data_ptr(), out.data_ptr(),
+                                            out.stride(0), x2.shape[0], n, k, _dt(x), int(shape), _stream()),
+               "mv_gate_up_silu_small_m")
     return out.view(*x.shape[:-1], n)
 
 

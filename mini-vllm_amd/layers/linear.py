@@ -1,7 +1,8 @@
 """Tensor-parallel linear layers (mirror of minivllm/models/layers/linear.py:36-319).
 Prefill GEMMs stay on hipBLASLt through ``F.linear``.  Decode steps go to the hand-written kernels:
   * up to ``SMALL_M_MAX`` tokens every projection is a pure HBM stream of its weights
-    (csrc/linear_small_m.hip, row-major weights);
+    (csrc/linear_small_m.hip; on the fragment-ordered copy below when there is one — whole-line loads —
+    else on the row-major weights);
   * up to ``MID_M_MAX`` tokens (the headline batch, 256) the projections are bound by how fast a CU takes bytes
     in; csrc/linear_mid_m.hip streams a fragment-ordered copy of the weight (``pack_for_decode``), with
     SiluAndMul in the gate_up epilogue and, for the row-parallel layers, a K split whose fp32 partial sums are
@@ -126,7 +127,7 @@ def linear(x, weight, bias=None, packed=None, kind: str = "col"):
     """``F.linear`` semantics; decode-sized inputs take the HIP kernels.  ``kind == 'row'`` may return a
     ``PartialSum`` (the caller hands it to the RMSNorm behind the projection)."""
     if small_m(x, weight):
-        return hip_ops.linear_small_m(x, weight, bias)
+        return hip_ops.linear_small_m(x, weight, bias, packed=packed)
     if mid_m(x, packed):
         n, k = weight.shape
         if hip_ops.linear_mid_m_ok(x, n):
@@ -162,12 +163,13 @@ class LinearBase(nn.Module):
         raise NotImplementedError("Subclasses must implement forward method")
 
     def pack_for_decode(self) -> bool:
-        """(Re)build the fragment-ordered copy of the weight that decode batches of 17..MID_M_MAX rows stream
-        (csrc/linear_mid_m.hip).  Call after the weights are loaded / whenever they change.  Costs one more
-        copy of the weight in HBM; prefill keeps reading the row-major one through the library GEMM."""
+        """(Re)build the fragment-ordered copy of the weight that decode steps stream (csrc/linear_small_m.hip up
+        to 16-32 rows, csrc/linear_mid_m.hip up to MID_M_MAX).  Call after the weights are loaded / whenever they
+        change.  Costs one more copy of the weight in HBM; prefill keeps reading the row-major one through the
+        library GEMM."""
         w = self.weight
         ok = (w.is_cuda and w.dtype in (torch.bfloat16, torch.float16) and w.shape[1] % 64 == 0
-              and w.shape[0] % 4 == 0 and MID_M_MAX > 0)
+              and w.shape[0] % 4 == 0)
         self.weight_packed = hip_ops.pack_weight(w.data) if ok else None
         return ok
 

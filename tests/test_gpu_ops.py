@@ -514,6 +514,45 @@ def test_linear_small_m(H, dtype, m, n, k, bias):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k,bias", [
+    (1, 2048, 2048, False), (1, 4608, 3584, True), (2, 2048, 6144, False), (3, 40, 256, True), (4, 3584, 18944, False),
+    (16, 4096, 2048, True), (17, 2064, 288, False), (33, 1000, 2048 + 32, True), (5, 151936, 1024, False),
+])
+def test_linear_small_m_on_the_packed_weight(H, dtype, m, n, k, bias):
+    """mv_linear_small_m_packed: the same projection streamed from the fragment-ordered copy (mv_pack_weight) —
+    within 1 ulp of the exact result like the row-major kernel, ragged N (zero-padded tiles) included."""
+    x = _randn(m, k, dtype=dtype, seed=m + n).to(DEV)
+    w = (_randn(n, k, dtype=torch.float32, seed=n + k) * k ** -0.5).to(dtype).to(DEV)
+    b = _randn(n, dtype=dtype, seed=3).to(DEV) if bias else None
+    wp = H.pack_weight(w)
+    exact = O.linear(x.cpu(), w.cpu(), None if b is None else b.cpu())
+    got = H.linear_small_m(x, w, b, packed=wp)
+    assert got.shape == (m, n) and got.dtype == dtype
+    ok, worst = _ulp_ok(got.cpu(), exact, dtype, 1.0)
+    assert ok, worst
+    # against the row-major kernel: equal but for results whose fp32 sums were cut into different K slices
+    plain = H.linear_small_m(x, w, b)
+    assert (got != plain).float().mean().item() < 0.02
+    # a weight that is not the packed copy of `weight` is refused by size, not silently used
+    assert torch.equal(H.linear_small_m(x, w, b, packed=wp.view(-1)[:-8]), plain)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,inter,k", [(1, 6144, 2048), (4, 18944, 3584), (16, 1008, 512)])
+def test_gate_up_silu_small_m_on_the_packed_weight(H, dtype, m, inter, k):
+    x = _randn(m, k, dtype=dtype, seed=m).to(DEV)
+    w = (_randn(2 * inter, k, dtype=torch.float32, seed=inter) * k ** -0.5).to(dtype).to(DEV)
+    got = H.gate_up_silu_small_m(x, w, packed=H.pack_weight(w))
+    want = O.gate_up_silu(x.cpu(), w.cpu(), dtype).double()
+    # (a GEMM output that lands on the other side of a rounding boundary moves the product by up to ~3 ulp; 4 with
+    #  the K slices cut differently from the row-major kernel's)
+    ok, worst = _ulp_ok(got.cpu(), want, dtype, 4.0)
+    assert ok, worst
+    ok, worst = _ulp_ok(got.cpu(), H.gate_up_silu_small_m(x, w).cpu().double(), dtype, 4.0)
+    assert ok, worst
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,inter,k", [(1, 6144, 2048), (4, 18944, 3584), (16, 1000, 512), (40, 16400, 256)])
 def test_gate_up_silu_small_m(H, dtype, m, inter, k):
     x = _randn(m, k, dtype=dtype, seed=m).to(DEV)

@@ -49,9 +49,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--models", default="qwen3-1.7b,qwen2-7b")
     ap.add_argument("--ms", default="1,8,16,32,64")
+    ap.add_argument("--no-sweep-packed", action="store_true")
     ap.add_argument("--only", default="")
     ap.add_argument("--xlds", type=int, default=0, help="1 / -1: force x through LDS on / off")
     ap.add_argument("--wlds", type=int, default=0, help="1 / -1: force W through LDS on / off")
+    ap.add_argument("--packed", action="store_true", help="also time the kernel on the fragment-ordered weight copy (and sweep its launch shape)")
     ap.add_argument("--sweep", action="store_true", help="sweep row tiles per wave x waves per shape (explicit launch-shape argument)")
     a = ap.parse_args()
     dev = torch.device("cuda")
@@ -87,8 +89,38 @@ def main():
                     print(f"   sweep {name} M={m}: " + "  ".join(f"r{r}w{w}={t:.1f}" for t, r, w in res[:6]), flush=True)
                 forced = hip_ops.small_m_shape(0, 0, a.xlds, a.wlds)
                 t_mv = timed(lambda i: hip_ops.linear_small_m(x, ws[i % copies], bias, forced), ncall)
+                tail = ""
+                if a.packed:
+                    wps = [hip_ops.pack_weight(w) for w in ws]
+                    same = torch.equal(hip_ops.linear_small_m(x, ws[0], bias, packed=wps[0]), hip_ops.linear_small_m(x, ws[0], bias))
+                    t_pk = timed(lambda i: hip_ops.linear_small_m(x, ws[i % copies], bias, 0, wps[i % copies]), ncall)
+                    res = []
+                    for rpw in (() if a.no_sweep_packed else (1, 2)):
+                        for waves in (2, 4, 6, 7, 8, 12, 14, 16):
+                            if waves * rpw * ((m + 15) // 16) > 64:
+                                continue
+                            shape = hip_ops.small_m_shape(rpw, waves)
+                            res.append((timed(lambda i: hip_ops.linear_small_m(x, ws[i % copies], bias, shape, wps[i % copies]), ncall), rpw, waves))
+                    res.sort()
+                    tail = (f" | packed {t_pk:7.2f} us {wbytes/t_pk/1e6:5.2f} TB/s same={same} best " +
+                            " ".join(f"r{r}w{w}={t:.1f}" for t, r, w in res[:7]))
+                    del wps
                 print(f"{model:11s} {name:8s} {m:3d} {n:7d} {k:6d} {wbytes/1e6:7.1f} | {t_lib:8.2f} {wbytes/t_lib/1e6:6.2f} | "
-                      f"{t_mv:8.2f} {wbytes/t_mv/1e6:6.2f} | {t_lib/t_mv:5.2f} {err:.3g} (lib {err_lib:.3g})", flush=True)
+                      f"{t_mv:8.2f} {wbytes/t_mv/1e6:6.2f} | {t_lib/t_mv:5.2f} {err:.3g} (lib {err_lib:.3g}){tail}", flush=True)
+                if a.packed and name == "gate_up":
+                    # the gated form the models actually run (gate_up + SiluAndMul): row-major vs packed, launch shapes
+                    wps = [hip_ops.pack_weight(w) for w in ws]
+                    t_rm = timed(lambda i: hip_ops.gate_up_silu_small_m(x, ws[i % copies]), ncall)
+                    t_pk = timed(lambda i: hip_ops.gate_up_silu_small_m(x, ws[i % copies], 0, wps[i % copies]), ncall)
+                    res = []
+                    for rpw in (1, 2):
+                        for waves in (2, 4, 7, 8, 14, 16):
+                            shape = hip_ops.small_m_shape(rpw, waves)
+                            res.append((timed(lambda i: hip_ops.gate_up_silu_small_m(x, ws[i % copies], shape, wps[i % copies]), ncall), rpw, waves))
+                    res.sort()
+                    print(f"{model:11s} gated    {m:3d} {n // 2:7d} {k:6d} {wbytes/1e6:7.1f} | row-major {t_rm:7.2f} us | packed {t_pk:7.2f} us "
+                          f"{wbytes/t_pk/1e6:5.2f} TB/s best " + " ".join(f"r{r}w{w}={t:.1f}" for t, r, w in res[:7]), flush=True)
+                    del wps
             del ws
 
 
