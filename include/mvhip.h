@@ -215,6 +215,27 @@ int mv_gate_up_silu_small_m_packed(const void *x, int64_t x_stride, const void *
                                    void *out, int64_t out_stride, int m, int n_inter,
                                    int k, int dtype, int shape, void *stream);
 
+/* K6 + K10 — the RMSNorm in front of a projection folded into the projection's launch, for decode steps of <= 4
+ * rows (K <= 2048; 2 rows to 4096, 1 row to 8192): every workgroup re-enacts the norm of those few rows in its
+ * prologue (the arithmetic of mv_rmsnorm / mv_add_rmsnorm thread for thread), so the step loses two launches per
+ * layer.  Replaces RMSNorm.forward followed by the F.linear of qkv_proj / gate_up_proj
+ * (minivllm/models/qwen_base.py:266-279 with layers/layernorm.py:81-105 and layers/linear.py:130,163).
+ *   residual == NULL: out = Linear(RMSNorm(x))
+ *   else:             residual_out = x + residual (rounded to dtype), out = Linear(RMSNorm(x + residual));
+ *                     residual_out must not alias residual (other workgroups still read the old rows).
+ * Results are bit-identical to the two-launch sequence on the packed weight.  MV_E_SHAPE when the fused form does
+ * not take the shape — the caller then issues the two launches. */
+int mv_norm_linear_small_m_packed(const void *x, int64_t x_stride, const void *residual,
+                                  int64_t res_stride, void *residual_out, int64_t res_out_stride,
+                                  const void *norm_w, float eps, const void *w_packed, const void *bias,
+                                  void *out, int64_t out_stride, int m, int n, int k, int dtype,
+                                  int shape, void *stream);
+int mv_norm_gate_up_silu_small_m_packed(const void *x, int64_t x_stride, const void *residual,
+                                        int64_t res_stride, void *residual_out, int64_t res_out_stride,
+                                        const void *norm_w, float eps, const void *w_gate_up_packed,
+                                        void *out, int64_t out_stride, int m, int n_inter, int k,
+                                        int dtype, int shape, void *stream);
+
 /* K11 — decode-batch linear layer for 17..512 rows (the headline batch, max_num_seqs = 256): same contract as
  * mv_linear_small_m (fp32 accumulation, bias in fp32, one rounding) with K % 64 == 0, N % 4 == 0.  Replaces the
  * F.linear calls of minivllm/models/layers/linear.py:130,163,316 where the library GEMM is bound by how fast a CU

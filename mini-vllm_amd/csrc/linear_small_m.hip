@@ -38,7 +38,92 @@ struct LinearParams {
   void *out;
   int64_t x_stride, out_stride;
   int M, N, K;  // N = output columns (GATED: W has 2N rows, up rows start at row N)
+  // NORM: x is the input of the RMSNorm in front of the projection (see norm_prologue)
+  const void *nres = nullptr, *nw = nullptr;
+  void *nres_out = nullptr;
+  int64_t nres_stride = 0, nres_out_stride = 0;
+  float eps = 0.f;
+  int norm_threads = 0;  // block size of the rmsnorm_kernel launch this prologue re-enacts
 };
+
+constexpr int kNormRedBytes = 256;  // [4 rows][16 waves] floats in front of the normalised rows
+__host__ __device__ constexpr int norm_row_bytes(int k) { return k * 2 + 64; }  // (+64: rows 0..3 on disjoint banks)
+
+// NORM prologue: the residual-add + RMSNorm that the reference runs in front of this projection
+// (minivllm/models/layers/layernorm.py:81-105; rmsnorm.hip) re-enacted by EVERY workgroup for the <= 4 rows of a
+// small decode step — a few KB from L2 — so that the norm needs no launch of its own.  The arithmetic is
+// rmsnorm_kernel's, thread for thread: a block of `norm_threads` threads, thread t owning the 8-element vectors
+// t, t + T, ..., the same fmaf chain, wave_sum, and wave-order sum, the same rounding points (the norm is taken
+// of the unrounded fp32 sum x + residual; the rounded sum is the new residual, written by workgroup 0 only and
+// to a buffer of its own: the other workgroups still read the old one).  The normalised rows land in LDS.
+template <typename Tag, int PT>
+__device__ __forceinline__ void norm_prologue(const LinearParams &p, float *nred, char *xs) {
+  constexpr int ROWS = 4 / PT;
+  const int T = p.norm_threads, nvec = p.K >> 3, tid = threadIdx.x, nw = T >> 6;
+  const uint16_t *x = (const uint16_t *)p.x, *res = (const uint16_t *)p.nres, *w = (const uint16_t *)p.nw;
+  uint16_t *res_out = (uint16_t *)p.nres_out;
+  const bool add = res != nullptr;
+  u32x4 xraw[ROWS][PT], rraw[ROWS][PT], wraw[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int c = tid + i * T;
+    const bool live = tid < T && c < nvec;
+    wraw[i] = live ? *(const u32x4 *)(w + c * 8) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const bool on = live && r < p.M;
+      xraw[r][i] = on ? *(const u32x4 *)(x + (int64_t)r * p.x_stride + c * 8) : u32x4{0u, 0u, 0u, 0u};
+      rraw[r][i] = on && add ? *(const u32x4 *)(res + (int64_t)r * p.nres_stride + c * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  float vals[ROWS][PT][8];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int c = tid + i * T;
+      const bool on = tid < T && c < nvec && r < p.M;
+      unpack8<Tag>(xraw[r][i], vals[r][i]);
+      if (add) {
+        float rr[8];
+        unpack8<Tag>(rraw[r][i], rr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vals[r][i][j] = __fadd_rn(vals[r][i][j], rr[j]);
+        if (on && blockIdx.x == 0) *(u32x4 *)(res_out + (int64_t)r * p.nres_out_stride + c * 8) = pack8<Tag>(vals[r][i]);
+      }
+      if (on) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss = fmaf(vals[r][i][j], vals[r][i][j], ss);
+      }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0 && (tid >> 6) < nw) nred[r * 16 + (tid >> 6)] = ss;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    if (r < p.M && tid < T) {
+      float t = nred[r * 16];
+      for (int i = 1; i < nw; ++i) t += nred[r * 16 + i];   // block_sum: 0.f + red[0] + red[1] + ...
+      const float var = t / (float)p.K;
+      const float rs = 1.0f / sqrtf(var + p.eps);
+#pragma unroll
+      for (int i = 0; i < PT; ++i) {
+        const int c = tid + i * T;
+        if (c < nvec) {
+          float wv[8], y[8];
+          unpack8<Tag>(wraw[i], wv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) y[j] = __fmul_rn(__fmul_rn(vals[r][i][j], rs), wv[j]);
+          *(u32x4 *)(xs + r * norm_row_bytes(p.K) + c * 16) = pack8<Tag>(y);
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
 
 // k steps (32 elements each) whose loads are issued together before the first MFMA
 // (16–20 wave-wide loads in flight per wave)
@@ -52,9 +137,10 @@ __host__ __device__ constexpr int unroll_of(int rpw, int mt) { return rpw + mt <
 // PACKED: W is the fragment-ordered copy mv_pack_weight makes for the decode-batch kernel ([N/16][K/32][64 lanes][8]:
 // the A fragment of a (16-row tile, k step) is 1 KiB of contiguous memory and a wave's K slice of a tile one
 // contiguous run), read non-temporally: every load instruction is a whole-line burst instead of 16 pieces of 64 B.
-template <typename Tag, int RPW, int MT, bool GATED, bool XLDS, bool WLDS = false, bool PACKED = false>
+template <typename Tag, int RPW, int MT, bool GATED, bool XLDS, bool WLDS = false, bool PACKED = false, bool NORM = false>
 __global__ void __launch_bounds__((GATED ? 2 : 1) * RPW * MT >= 12 ? 512 : 1024)
-linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of partial-tile LDS allow <= 5 waves)
+linear_small_m_kernel(LinearParams p) {
+  static_assert(!NORM || (PACKED && MT == 1 && !XLDS), "the norm prologue exists for the packed, <= 16-row form");  // (>= 12 tiles per wave: the 64 KB of partial-tile LDS allow <= 5 waves)
   typedef uint16_t T;
   extern __shared__ float red[];  // [waves][RPW*MT][64][4]; XLDS: first the per-wave x blocks
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -104,6 +190,27 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
   for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char *xs_row = nullptr;  // NORM: this lane's normalised row in LDS (+ its k-group offset)
+  // NORM: the first weight block of this wave's K slice is requested BEFORE the norm prologue — the weights do
+  // not depend on it, and the prologue's two L2 round trips then hide behind the HBM latency of the stream
+  u32x4 wf0[NORM ? kUnroll : 1][NORM ? NA : 1];
+  if constexpr (NORM) {
+    if (s_lo < s_hi) {
+      int sb = s_lo + kUnroll <= s_hi ? s_lo : s_hi - kUnroll;
+      sb = sb < 0 ? 0 : sb;
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+          wf0[u][a] = __builtin_nontemporal_load((const u32x4 *)(wp[a] + (int64_t)(sb + u) * WSTEP));
+    }
+    char *xs = (char *)red + kNormRedBytes;
+    const int pt = ((p.K >> 3) + p.norm_threads - 1) / p.norm_threads;
+    if (pt <= 1) norm_prologue<Tag, 1>(p, red, xs);
+    else if (pt == 2) norm_prologue<Tag, 2>(p, red, xs);
+    else norm_prologue<Tag, 4>(p, red, xs);
+    xs_row = xs + (r16 < p.M ? r16 : p.M - 1) * norm_row_bytes(p.K) + g * 16;
+  }
 
   // blocks of kUnroll k-steps, all loads of a block issued before its first MFMA; the last block of a
   // slice is shifted back to end at the slice's end and feeds zeros for the steps already done (no
@@ -138,13 +245,18 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
       if constexpr (!WLDS) {
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-          if constexpr (PACKED)
+          if constexpr (NORM) {
+            if (s == s_lo) wf[u][a] = wf0[u][a];   // (wave-uniform)
+            else wf[u][a] = __builtin_nontemporal_load((const u32x4 *)(wp[a] + (int64_t)(sb + u) * WSTEP));
+          } else if constexpr (PACKED)
             wf[u][a] = __builtin_nontemporal_load((const u32x4 *)(wp[a] + (int64_t)(sb + u) * WSTEP));
           else
             wf[u][a] = *(const u32x4 *)(wp[a] + sb * 32 + u * 32);
         }
       }
-      if constexpr (!XLDS) {
+      if constexpr (NORM) {
+        xf[u][0] = *(const u32x4 *)(xs_row + (sb + u) * 64);
+      } else if constexpr (!XLDS) {
 #pragma unroll
         for (int b = 0; b < MT; ++b) xf[u][b] = *(const u32x4 *)(xp[b] + sb * 32 + u * 32);
       }
@@ -196,7 +308,7 @@ linear_small_m_kernel(LinearParams p) {  // (>= 12 tiles per wave: the 64 KB of 
   // partial tiles -> LDS, then output tile t of the workgroup is finished by wave t % nwaves
   constexpr int NT = NA * MT;
   f32x4 *red4 = (f32x4 *)red;
-  if constexpr (XLDS || WLDS) __syncthreads();  // the partial tiles overwrite the blocks of other waves
+  if constexpr (XLDS || WLDS || NORM) __syncthreads();  // the partial tiles overwrite the blocks / rows other waves read
 #pragma unroll
   for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -271,8 +383,17 @@ int launch(const LinearParams &p, int rpw, int mt, dim3 grid, dim3 block, size_t
 // take 2-4 row tiles per wave.  K slices per workgroup: enough waves that the chip holds >= ~2048 of
 // them, each slice at least one full block of k-steps (two for the last doubling).  Measured choices:
 // tools/bench_linear.py --sweep.
-template <bool GATED, bool PACKED = false>
-int run(const LinearParams &p, int dtype, int shape, hipStream_t st) {
+// the block size launch_rmsnorm (rmsnorm.hip) gives a row of `cols` 16-bit elements, and 16-byte vectors per thread
+static void norm_block(int cols, int *threads, int *per_thread) {
+  const int nvec = cols / 8;
+  int t = (nvec + 63) / 64 * 64;
+  if (t > 256) t = nvec > 1024 ? 1024 : 256;
+  *threads = t;
+  *per_thread = (nvec + t - 1) / t;
+}
+
+template <bool GATED, bool PACKED = false, bool NORM = false>
+int run(LinearParams p, int dtype, int shape, hipStream_t st) {
   const int m = p.M, n = p.N, mt = (m + 15) / 16, steps = p.K / 32;
   int rpw = GATED ? (m > 2 && n >= 16384 ? 2 : 1) : (m <= 2 ? 1 : (n >= 65536 ? 4 : (n >= 8192 ? 2 : 1)));
   // (on the packed copy 4 row tiles per wave never measured fastest, nor 2 + 2 tiles for the gated form:
@@ -305,6 +426,31 @@ int run(const LinearParams &p, int dtype, int shape, hipStream_t st) {
   const int force_waves = (shape >> 4) & 31;
   if (force_waves >= 1 && force_waves <= 16 && force_waves * na * mt <= 64) waves = force_waves;
   while (waves > 1 && waves * na * mt > 64) waves /= 2;  // 64 KB of LDS for the partial tiles
+  if constexpr (NORM) {
+    int nt, npt;
+    norm_block(p.K, &nt, &npt);
+    const int pt = npt <= 1 ? 1 : (npt == 2 ? 2 : 4);
+    if (mt != 1 || npt > 4 || m * pt > 4 || waves * 64 < nt || (p.K & 7)) return MV_E_SHAPE;
+    p.norm_threads = nt;
+    size_t lds = (size_t)waves * na * 64 * sizeof(f32x4);
+    const size_t need = kNormRedBytes + (size_t)m * norm_row_bytes(p.K);
+    if (need > lds) lds = need;
+    if (lds > 65536) return MV_E_SHAPE;
+    dim3 grid(tiles), block(waves * 64);
+#define MV_NORM(TAG)                                                                                                  \
+  do {                                                                                                                \
+    if (rpw == 2 && !GATED)                                                                                           \
+      hipLaunchKernelGGL((linear_small_m_kernel<TAG, GATED ? 1 : 2, 1, GATED, false, false, true, true>), grid, block, lds, st, p); \
+    else                                                                                                              \
+      hipLaunchKernelGGL((linear_small_m_kernel<TAG, 1, 1, GATED, false, false, true, true>), grid, block, lds, st, p); \
+  } while (0)
+    if (rpw != 1 && rpw != 2) return MV_E_SHAPE;
+    if (dtype == MV_BF16) MV_NORM(bf16_tag);
+    else MV_NORM(f16_tag);
+#undef MV_NORM
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+  }
   // x through LDS once its fragment-shaped loads weigh: from 12 rows up, unless 4 row tiles per wave already
   // amortise them (measured, tools/dbg/xlds_bench.sh: M=16 +5..17 % on the 8-34 MB layers, -15 % on the LM
   // head with RPW 4; M=32 +7..30 % everywhere; M <= 8 -1..-10 %)
@@ -401,4 +547,49 @@ extern "C" int mv_gate_up_silu_small_m_packed(const void *x, int64_t x_stride, c
   if (int e = check(x, x_stride, w_gate_up_packed, nullptr, out, out_stride, m, n_inter, k, dtype)) return e;
   LinearParams p{x, w_gate_up_packed, nullptr, out, x_stride, out_stride, m, n_inter, k};
   return run<true, true>(p, dtype, shape, (hipStream_t)stream);
+}
+
+// The RMSNorm in front of a projection, folded into the projection's launch (<= 4 rows; see norm_prologue):
+//   residual == NULL:  out = Linear(RMSNorm(x))                                   (the first layer's input norm)
+//   else:              residual_out = x + residual;  out = Linear(RMSNorm(x + residual))   (add_rms_forward)
+// with every value bit-identical to mv_rmsnorm / mv_add_rmsnorm followed by mv_linear_small_m_packed.
+// MV_E_SHAPE when the fused form does not take the shape: the caller then launches the two kernels.
+static int norm_check(const void *x, int64_t x_stride, const void *residual, int64_t res_stride, void *residual_out,
+                      int64_t res_out_stride, const void *norm_w, int m, int k) {
+  if (!norm_w || (residual && !residual_out)) return MV_E_NULLPTR;
+  if (m > 4 || k > 8192) return MV_E_SHAPE;
+  if (!mv_aligned16(norm_w) || (residual && (!mv_aligned16(residual) || !mv_aligned16(residual_out) ||
+                                             (res_stride & 7) || (res_out_stride & 7))))
+    return MV_E_ALIGN;
+  if (residual && residual_out == residual) return MV_E_ALIGN;  // the other workgroups still read the old rows
+  return MV_OK;
+}
+
+extern "C" int mv_norm_linear_small_m_packed(const void *x, int64_t x_stride, const void *residual,
+                                             int64_t res_stride, void *residual_out, int64_t res_out_stride,
+                                             const void *norm_w, float eps, const void *w_packed, const void *bias,
+                                             void *out, int64_t out_stride, int m, int n, int k, int dtype,
+                                             int shape, void *stream) {
+  if (m == 0 || n == 0) return MV_OK;
+  if (int e = check(x, x_stride, w_packed, bias, out, out_stride, m, n, k, dtype)) return e;
+  if (int e = norm_check(x, x_stride, residual, res_stride, residual_out, res_out_stride, norm_w, m, k)) return e;
+  LinearParams p{x, w_packed, bias, out, x_stride, out_stride, m, n, k};
+  p.nres = residual, p.nw = norm_w, p.nres_out = residual_out;
+  p.nres_stride = res_stride, p.nres_out_stride = res_out_stride, p.eps = eps;
+  return run<false, true, true>(p, dtype, shape, (hipStream_t)stream);
+}
+
+extern "C" int mv_norm_gate_up_silu_small_m_packed(const void *x, int64_t x_stride, const void *residual,
+                                                   int64_t res_stride, void *residual_out, int64_t res_out_stride,
+                                                   const void *norm_w, float eps, const void *w_gate_up_packed,
+                                                   void *out, int64_t out_stride, int m, int n_inter, int k,
+                                                   int dtype, int shape, void *stream) {
+  if (m == 0 || n_inter == 0) return MV_OK;
+  if (n_inter & 15) return MV_E_SHAPE;
+  if (int e = check(x, x_stride, w_gate_up_packed, nullptr, out, out_stride, m, n_inter, k, dtype)) return e;
+  if (int e = norm_check(x, x_stride, residual, res_stride, residual_out, res_out_stride, norm_w, m, k)) return e;
+  LinearParams p{x, w_gate_up_packed, nullptr, out, x_stride, out_stride, m, n_inter, k};
+  p.nres = residual, p.nw = norm_w, p.nres_out = residual_out;
+  p.nres_stride = res_stride, p.nres_out_stride = res_out_stride, p.eps = eps;
+  return run<true, true, true>(p, dtype, shape, (hipStream_t)stream);
 }

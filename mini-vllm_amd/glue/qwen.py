@@ -10,8 +10,10 @@ Qwen3 = no bias, per-head q/k RMSNorm, theta 1e4 default (qwen2.py:23-25, qwen3.
 """
 from __future__ import annotations
 
+import os
 from typing import Any
 
+import torch
 from torch import nn
 
 from .. import hip_ops
@@ -43,6 +45,53 @@ def _rope_scaling(config) -> dict[str, Any] | None:
     keep = {"factor", "type", "low_freq_factor", "high_freq_factor", "original_max_position_embeddings",
             "short_factor", "long_factor"}
     return {k: v for k, v in raw.items() if k in keep} or None
+
+
+class PendingNorm:
+    """The input of a layer norm whose launch is folded into the projection behind it (decode steps of <= 4 rows,
+    hip_ops.norm_linear_small_m): ``x`` (+ ``residual``) and the norm's weight / eps.  The projection that consumes
+    it leaves the new residual in ``residual_out``."""
+    __slots__ = ("x", "residual", "norm", "residual_out")
+
+    def __init__(self, x, residual, norm):
+        self.x, self.residual, self.norm, self.residual_out = x, residual, norm, None
+
+    @property
+    def shape(self):
+        return self.x.shape
+
+    def dim(self):
+        return self.x.dim()
+
+    def project(self, lin, gated: bool = False):
+        """RMSNorm + ``lin`` (a LinearBase with a packed weight) in one launch; None when the kernel declines the
+        shape (the caller then reads ``materialize()``)."""
+        n = lin.weight.shape[0] // 2 if gated else lin.weight.shape[0]
+        got = hip_ops.norm_linear_small_m(self.x, self.residual, self.norm.weight, self.norm.eps, lin.weight_packed,
+                                          n, None if gated else lin.bias, gated)
+        if got is None:
+            return None
+        out, self.residual_out = got
+        return out
+
+    def materialize(self):
+        """The norm as a launch of its own."""
+        if self.residual is None:
+            self.residual_out = self.x
+            return self.norm(self.x)[0]
+        h, self.residual_out = self.norm(self.x, self.residual)
+        return h
+
+
+def _fold_norm(x, residual, lin) -> bool:
+    """Fold the layer norm in front of ``lin`` into its launch?  Single GPU, 2-D activations of <= 4 rows whose
+    projection runs on the packed weight (csrc/linear_small_m.hip, norm_prologue)."""
+    return (NORM_FOLD and torch.is_tensor(x) and get_tensor_parallel_world_size() == 1
+            and (residual is None or torch.is_tensor(residual))
+            and small_m(x, lin.weight) and hip_ops.norm_linear_small_m_ok(x, lin.weight.shape[0], lin.weight_packed))
+
+
+NORM_FOLD = os.environ.get("MV_NORM_FOLD", "1") != "0"
 
 
 class QwenAttention(nn.Module):
@@ -83,7 +132,12 @@ class QwenAttention(nn.Module):
             hidden_states = hidden_states.reshape(-1, hidden_states.shape[-1])
             positions = positions.reshape(-1)
         t = hidden_states.shape[0]
-        qkv = self.qkv_proj(hidden_states)
+        if isinstance(hidden_states, PendingNorm):   # the input norm rides in the qkv launch
+            qkv = hidden_states.project(self.qkv_proj)
+            if qkv is None:
+                qkv = self.qkv_proj(hidden_states.materialize())
+        else:
+            qkv = self.qkv_proj(hidden_states)
         q = qkv[:, :self.q_size].view(t, self.num_heads, self.head_dim)
         k = qkv[:, self.q_size:self.q_size + self.kv_size].view(t, self.num_kv_heads, self.head_dim)
         v = qkv[:, self.q_size + self.kv_size:].view(t, self.num_kv_heads, self.head_dim)
@@ -122,6 +176,11 @@ class QwenMLP(nn.Module):
     def forward(self, x, reduce: bool = True):
         w, gu = self.gate_up_proj.weight, self.gate_up_proj
         flat = x.dim() == 2
+        if isinstance(x, PendingNorm):   # the post-attention norm rides in the gate_up launch
+            act = x.project(gu, gated=True)
+            if act is not None:
+                return self.down_proj(act, reduce=reduce, partial_ok=flat)
+            x = x.materialize()
         if small_m(x, w):  # decode-sized batch: SiluAndMul in the epilogue of the weight-streaming gate_up kernel
             return self.down_proj(hip_ops.gate_up_silu_small_m(x, w, packed=gu.weight_packed), reduce=reduce,
                                   partial_ok=flat)
@@ -155,6 +214,13 @@ class QwenDecoderLayer(nn.Module):
         parallel): its all-reduce runs fused with this layer's input norm.  Under TP the layer defers both of
         its own all-reduces the same way and returns the un-reduced MLP output (see ``defers_reduce``)."""
         ln1, ln2, defer = self.input_layernorm, self.post_attention_layernorm, self.defers_reduce
+        if not pending_reduce and _fold_norm(hidden_states, residual, self.self_attn.qkv_proj) \
+                and _fold_norm(hidden_states, residual, self.mlp.gate_up_proj):
+            # decode steps of <= 4 rows: both norms ride in the launches of the projections behind them
+            pend = PendingNorm(hidden_states, residual, ln1)
+            hidden_states = self.self_attn(positions, pend, reduce=True)
+            pend = PendingNorm(hidden_states, pend.residual_out, ln2)
+            return self.mlp(pend, reduce=True), pend.residual_out
         if residual is None:
             residual = hidden_states
             hidden_states, _ = ln1(hidden_states)

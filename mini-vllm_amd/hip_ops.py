@@ -57,6 +57,12 @@ _SIGNATURES = {
                                          c_int, c_int, c_int, c_void_p]),
     "mv_gate_up_silu_small_m_packed": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                                c_int, c_int, c_void_p]),
+    "mv_norm_linear_small_m_packed": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                              c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                              c_int, c_int, c_void_p]),
+    "mv_norm_gate_up_silu_small_m_packed": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                                    c_void_p, c_float, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                                    c_int, c_int, c_int, c_void_p]),
     "mv_packed_weight_elems": (c_size_t, [c_int, c_int]),
     "mv_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mv_linear_mid_m": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
@@ -472,6 +478,56 @@ def gate_up_silu_small_m(x, weight, shape: int = 0, packed=None):
                                             out.stride(0), x2.shape[0], n, k, _dt(x), int(shape), _stream()),
                "mv_gate_up_silu_small_m")
     return out.view(*x.shape[:-1], n)
+
+
+NORM_FUSED_MAX_ROWS = 4
+MV_E_SHAPE = -2   # include/mvhip.h
+
+
+def norm_linear_small_m_ok(x, n_rows_w: int, packed) -> bool:
+    """True when the norm-in-the-prologue form of the small-M projection takes ``x`` [rows, K] (rows x vectors per
+    norm thread <= 4, the packed weight present)."""
+    if not (x.is_cuda and x.dim() == 2 and x.dtype in (torch.bfloat16, torch.float16) and x.stride(1) == 1):
+        return False
+    rows, k = x.shape
+    if not 0 < rows <= NORM_FUSED_MAX_ROWS or k % 64 or k > 8192 or x.data_ptr() % 16 or x.stride(0) % 8:
+        return False
+    nvec = k // 8
+    threads = min(256, -(-nvec // 64) * 64)
+    per_thread = -(-nvec // threads)
+    pt = 1 if per_thread <= 1 else (2 if per_thread == 2 else 4)
+    return rows * pt <= 4 and _packed_ok(packed, n_rows_w, k, x.dtype)
+
+
+def norm_linear_small_m(x, residual, norm_weight, eps: float, weight_packed, n: int, bias=None, gated: bool = False):
+    """(RMSNorm -> projection) of a <= 4-row decode step in ONE launch.  x [rows, K]; residual [rows, K] | None.
+    Returns (out [rows, n], new_residual) — new_residual is ``x`` itself when residual is None (reference:
+    layernorm.py:81-105, the caller keeps x as the residual), else a fresh tensor holding x + residual.
+    gated: weight_packed is the packed merged [2n, K] gate_up matrix, out = silu(gate) * up.
+    Returns None when the kernel declines the shape (the caller then runs norm and projection separately)."""
+    _need_cuda(x, norm_weight, weight_packed)
+    rows, k = x.shape
+    out = torch.empty((rows, n), dtype=x.dtype, device=x.device)
+    nw = norm_weight if norm_weight.dtype == x.dtype else norm_weight.to(x.dtype)
+    if residual is not None:
+        r2 = residual if residual.is_contiguous() else residual.contiguous()
+        r2 = r2.view(rows, k)
+        res_out = torch.empty_like(r2)
+        rp, rs, rop, ros = r2.data_ptr(), r2.stride(0), res_out.data_ptr(), res_out.stride(0)
+    else:
+        res_out, rp, rs, rop, ros = x, None, 0, None, 0
+    if gated:
+        rc = _lib.mv_norm_gate_up_silu_small_m_packed(x.data_ptr(), x.stride(0), rp, rs, rop, ros, nw.data_ptr(),
+                                                      float(eps), weight_packed.data_ptr(), out.data_ptr(),
+                                                      out.stride(0), rows, n, k, _dt(x), 0, _stream())
+    else:
+        rc = _lib.mv_norm_linear_small_m_packed(x.data_ptr(), x.stride(0), rp, rs, rop, ros, nw.data_ptr(),
+                                                float(eps), weight_packed.data_ptr(), _ptr(bias), out.data_ptr(),
+                                                out.stride(0), rows, n, k, _dt(x), 0, _stream())
+    if rc == MV_E_SHAPE:
+        return None
+    _check(rc, "mv_norm_linear_small_m_packed")
+    return out, res_out
 
 
 # ---------------------------------------------------------------- K11

@@ -553,6 +553,59 @@ def test_gate_up_silu_small_m_on_the_packed_weight(H, dtype, m, inter, k):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k,bias,gated", [
+    (1, 4096, 2048, False, False), (4, 4096, 2048, True, False), (2, 4608, 3584, True, False),
+    (1, 1280, 8192, True, False), (3, 3072, 1024, False, False), (1, 6144, 2048, False, True),
+    (2, 18944, 3584, False, True), (4, 3072, 1024, False, True), (1, 152064, 3584, False, False),
+])
+@pytest.mark.parametrize("with_residual", [True, False])
+def test_norm_folded_into_the_small_m_projection_is_bit_identical(H, dtype, m, n, k, bias, gated, with_residual):
+    """mv_norm_linear_small_m_packed / mv_norm_gate_up_silu_small_m_packed: RMSNorm (+ residual add) in the
+    prologue of the projection == mv_(add_)rmsnorm followed by the projection on the packed weight, bit for bit
+    (outputs AND the new residual), and the residual input is left untouched."""
+    x = _randn(m, k, dtype=dtype, seed=m + n).to(DEV)
+    res = _randn(m, k, dtype=dtype, seed=7).to(DEV) if with_residual else None
+    nw = (1.0 + 0.1 * _randn(k, dtype=torch.float32, seed=3)).to(dtype).to(DEV)
+    rows_w = 2 * n if gated else n
+    w = (_randn(rows_w, k, dtype=torch.float32, seed=n + k) * k ** -0.5).to(dtype).to(DEV)
+    b = _randn(n, dtype=dtype, seed=5).to(DEV) if bias else None
+    wp = H.pack_weight(w)
+    assert H.norm_linear_small_m_ok(x, rows_w, wp)
+    eps = 1e-6
+    if with_residual:
+        h_ref, res_ref = H.add_rmsnorm(x, res, nw, eps, inplace=False)
+    else:
+        h_ref, res_ref = H.rmsnorm(x, nw, eps), x
+    want = H.gate_up_silu_small_m(h_ref, w, packed=wp) if gated else H.linear_small_m(h_ref, w, b, packed=wp)
+    res_before = None if res is None else res.clone()
+    got = H.norm_linear_small_m(x, res, nw, eps, wp, n, b, gated)
+    assert got is not None
+    out, res_out = got
+    assert torch.equal(out, want)
+    assert torch.equal(res_out, res_ref)
+    if res is not None:
+        assert torch.equal(res, res_before) and res_out.data_ptr() != res.data_ptr()
+    else:
+        assert res_out.data_ptr() == x.data_ptr()
+    # and against the oracle's norm + linear (the two-launch path is itself checked against it elsewhere)
+    if not gated:
+        exact = O.linear(h_ref.cpu(), w.cpu(), None if b is None else b.cpu())
+        ok, worst = _ulp_ok(out.cpu(), exact, dtype, 1.0)
+        assert ok, worst
+
+
+def test_norm_folding_declines_what_it_cannot_hold(H):
+    dtype = torch.bfloat16
+    w = torch.zeros(256, 3584, dtype=dtype, device=DEV)
+    wp = H.pack_weight(w)
+    assert not H.norm_linear_small_m_ok(torch.zeros(5, 3584, dtype=dtype, device=DEV), 256, wp)   # > 4 rows
+    assert not H.norm_linear_small_m_ok(torch.zeros(3, 3584, dtype=dtype, device=DEV), 256, wp)   # 3 rows x 2 vectors
+    assert H.norm_linear_small_m_ok(torch.zeros(2, 3584, dtype=dtype, device=DEV), 256, wp)
+    x = torch.zeros(3, 3584, dtype=dtype, device=DEV)
+    assert H.norm_linear_small_m(x, None, torch.ones(3584, dtype=dtype, device=DEV), 1e-6, wp, 256) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,inter,k", [(1, 6144, 2048), (4, 18944, 3584), (16, 1000, 512), (40, 16400, 256)])
 def test_gate_up_silu_small_m(H, dtype, m, inter, k):
     x = _randn(m, k, dtype=dtype, seed=m).to(DEV)

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -78,8 +79,11 @@ __global__ void __launch_bounds__(256) gemv(const uint16_t *__restrict__ w, cons
 
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(_e), __LINE__); return 1; } } while (0)
 
-int main() {
-  const int CHAIN = 224, NW = 48;  // launches per "step"; distinct weight matrices (384 MB > Infinity Cache)
+int main(int argc, char **argv) {
+  // launches per "step"; distinct weight matrices (48 x 8 MB = 384 MB > the 256 MB Infinity Cache; pass 12 to keep
+  // them all resident in it, 2 for L2-resident: what would a prefetcher buy?)
+  const int CHAIN = 224, NW = argc > 1 ? atoi(argv[1]) : 48;
+  const int MODES = argc > 2 ? atoi(argv[2]) : 3;
   std::vector<uint16_t *> w(NW);
   for (auto &p : w) { CK(hipMalloc(&p, (size_t)N * K * 2)); CK(hipMemset(p, 0x3c, (size_t)N * K * 2)); }
   uint16_t *xb[2]; unsigned *flags, *err;
@@ -102,7 +106,7 @@ int main() {
                            flags + (i + 1) % CHAIN, (i == 0 ? epoch - 1 : epoch) * WGS, err);
     }
   };
-  for (int mode = 0; mode < 3; ++mode) {
+  for (int mode = 0; mode < MODES; ++mode) {
     for (int graph = 0; graph < 2; ++graph) {
       CK(hipMemset(flags, 0, (CHAIN + 1) * sizeof(unsigned)));
       CK(hipDeviceSynchronize());
