@@ -42,6 +42,9 @@ class Config:
     # beyond the reference (opt-in): prompts longer than max_num_batched_tokens are prefilled in chunks
     # (scheduler.py); max_num_batched_tokens may then be smaller than max_model_len
     enable_chunked_prefill: bool = False
+    # beyond the reference (opt-in): a prefill step also carries one token of every running sequence (scheduler.py),
+    # so decoding does not stall while prompts are prefilled
+    enable_mixed_batches: bool = False
 
     @property
     def gpu_memory_utilization(self) -> float:

@@ -243,9 +243,13 @@ class InferenceExecutor:
 
     def _ship_prefill(self, inp: BatchInputs, sequences):
         set_context(True, inp.max_seqlen_q, inp.max_seqlen_k, self._to_dev(inp.cum_seqlens_q),
-                    self._to_dev(inp.cum_seqlens_k), self._to_dev(inp.slot_mapping), None,
+                    self._to_dev(inp.cum_seqlens_k), self._to_dev(inp.slot_mapping),
+                    self._to_dev(inp.context_lens) if inp.decode_rows else None,
                     self._to_dev(inp.block_tables),
-                    prefix_cached=any(s.num_cached_tokens > 0 for s in sequences))
+                    prefix_cached=any(s.num_cached_tokens > 0 for s in sequences),
+                    decode_rows=inp.decode_rows, rest_cum_seqlens_q=self._to_dev(inp.rest_cum_seqlens_q),
+                    rest_cum_seqlens_k=self._to_dev(inp.rest_cum_seqlens_k),
+                    rest_max_seqlen_q=inp.rest_max_seqlen_q, rest_max_seqlen_k=inp.rest_max_seqlen_k)
         return self._to_dev(inp.input_ids), self._to_dev(inp.positions)
 
     def _ship_decode(self, inp: BatchInputs):

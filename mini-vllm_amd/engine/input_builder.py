@@ -40,6 +40,12 @@ class BatchInputs:
     packed: bool = False          # ids/positions/slots/context_lens are views of InputBuilder.decode_pack
     tables_dirty: bool = True     # block-table staging changed since the previous decode batch
     batch_changed: bool = True    # different sequences (or order) than the previous decode batch
+    # mixed batch (prefill step whose first ``decode_rows`` sequences are decode rows; utils/context.py)
+    decode_rows: int = 0
+    rest_cum_seqlens_q: torch.Tensor | None = None
+    rest_cum_seqlens_k: torch.Tensor | None = None
+    rest_max_seqlen_q: int = 0
+    rest_max_seqlen_k: int = 0
 
 
 class InputBuilder:
@@ -53,7 +59,7 @@ class InputBuilder:
         # int64 plane: [input_ids | positions]; int32 plane: [slots | cu_q | cu_k / context_lens]
         self._i64 = self._alloc((2, cap_tok), torch.int64)
         self._slots = self._alloc((cap_tok,), torch.int32)
-        self._seq32 = self._alloc((3, max_num_seqs + 1), torch.int32)
+        self._seq32 = self._alloc((5, max_num_seqs + 1), torch.int32)
         self._tables = self._alloc((max_num_seqs, self.max_blocks_per_seq), torch.int32)
         self._np_i64 = self._i64.numpy()
         self._np_slots = self._slots.numpy()
@@ -101,11 +107,13 @@ class InputBuilder:
             cu_k.append(cu_k[-1] + n)
             max_q, max_k = max(max_q, n - cached), max(max_k, n)
             if seq.block_table:
-                first, last = seq.num_cached_blocks, -(-n // bs) - 1
+                # slots of tokens [cached, n): whole blocks for the reference's flows (cached is a multiple of the
+                # block size there); a decode row of a mixed batch starts inside its last block
+                first, last = cached // bs, -(-n // bs) - 1
                 for i in range(first, last + 1):
-                    start = seq.block_table[i] * bs
-                    count = bs if i != last else n - last * bs
-                    slots.append(np.arange(start, start + count, dtype=np.int32))
+                    lo, hi = max(cached, i * bs), min(n, (i + 1) * bs)
+                    start = seq.block_table[i] * bs + lo - i * bs
+                    slots.append(np.arange(start, start + hi - lo, dtype=np.int32))
         t = len(ids)
         out_ids = self._fit_i64(0, t)
         out_pos = self._fit_i64(1, t)
@@ -124,7 +132,24 @@ class InputBuilder:
         tables = None
         if any(seq.block_table for seq in sequences):
             tables = self._tables_for(sequences, decode=False)
-        return BatchInputs(True, out_ids, out_pos, max_q, max_k, cq, ck, slot_t, None, tables, n)
+        out = BatchInputs(True, out_ids, out_pos, max_q, max_k, cq, ck, slot_t, None, tables, n)
+        # leading sequences that add exactly one token to a cached prefix are decode rows (mixed batches)
+        nd = 0
+        while nd < n and sequences[nd].block_table and sequences[nd].num_cached_tokens > 0 \
+                and sequences[nd].prefill_stop - sequences[nd].num_cached_tokens == 1:
+            nd += 1
+        if nd:
+            ctx = self._fit_seq32(2, nd)
+            ctx.numpy()[:] = [s.prefill_stop for s in sequences[:nd]]
+            out.decode_rows, out.context_lens = nd, ctx
+            rq, rk = self._fit_seq32(3, n - nd + 1), self._fit_seq32(4, n - nd + 1)
+            rq.numpy()[:] = np.asarray(cu_q[nd:], dtype=np.int64) - cu_q[nd]
+            rk.numpy()[:] = np.asarray(cu_k[nd:], dtype=np.int64) - cu_k[nd]
+            out.rest_cum_seqlens_q, out.rest_cum_seqlens_k = rq, rk
+            rest = sequences[nd:]
+            out.rest_max_seqlen_q = max((s.prefill_stop - s.num_cached_tokens for s in rest), default=0)
+            out.rest_max_seqlen_k = max((s.prefill_stop for s in rest), default=0)
+        return out
 
     # ------------------------------------------------------------------ decode (a2)
     def decode(self, sequences: list[Sequence], pad_to: int | None = None) -> BatchInputs:

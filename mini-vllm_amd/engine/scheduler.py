@@ -8,7 +8,14 @@ Beyond the reference (BASELINE config 4 "chunked prefill"): a pro
 max_num_batched_tokens — which the reference can never schedule — is prefilled ALONE in chunks of at most
 max_num_batched_tokens tokens (whole blocks), one chunk per step, each attending the chunks before it through
 the paged KV cache (the prefix-cached form of the prefill kernel).  Only the last chunk's token is kept.  Every
-flow the reference supports schedules exactly as before (the host traces pin that)."""
+flow the reference supports schedules exactly as before (the host traces pin that).
+
+Mixed batches (``enable_mixed_batches``, also beyond the reference): a prefill step additionally carries ONE token of
+every running sequence — they come first in the batch, as "prompts" whose all-but-last tokens are cached
+(``num_cached_tokens = len - 1``), which is exactly what a decode row is; the input builder and the attention layer
+route such rows to the paged-decode kernel.  The projections then stream their weights once for prompt tokens and
+decode rows together, and decoding no longer stalls while prompts (or the chunks of a long one) are prefilled.  The
+token budget of the prompts shrinks by the number of decode rows."""
 from __future__ import annotations
 
 import logging
@@ -33,6 +40,7 @@ class Scheduler:
         self.max_model_len = min(getattr(config, "max_model_len", None) or (1 << 62),
                                  config.num_kvcache_blocks * config.kvcache_block_size)
         self.chunked_prefill = bool(getattr(config, "enable_chunked_prefill", False))
+        self.mixed_batches = bool(getattr(config, "enable_mixed_batches", False))
         self.waiting: deque[Sequence] = deque()
         self.running: deque[Sequence] = deque()
         self.prefilling: Sequence | None = None   # a long prompt between two of its chunks
@@ -47,6 +55,15 @@ class Scheduler:
     def schedule(self) -> tuple[list[Sequence], bool]:
         if self.is_finished():
             raise RuntimeError("No sequences scheduled")
+        if self.mixed_batches and self.running and self._prompt_could_join(len(self.running)):
+            rows = self._schedule_decode()                  # the reference's decode rules (may preempt)
+            prompts = self._schedule_prefill(len(rows)) if rows else []
+            if prompts:
+                for seq in rows:                            # a decode row = a prompt with one uncached token
+                    seq.num_cached_tokens, seq.prefill_end = len(seq) - 1, None
+                return rows + prompts, True
+            if rows:
+                return rows, False
         batch = self._schedule_prefill()
         if batch:
             return batch, True
@@ -64,28 +81,46 @@ class Scheduler:
             raise RuntimeError(msg)
         return [], False
 
-    def _next_chunk(self, seq: Sequence) -> None:
-        """Set the token range [num_cached_tokens, prefill_end) of the next chunk of a long prompt."""
+    def _next_chunk(self, seq: Sequence, used: int = 0) -> None:
+        """Set the token range [num_cached_tokens, prefill_end) of the next chunk of a long prompt (``used``: tokens
+        of the step already taken by decode rows)."""
         bs = self.block_manager.block_size
-        budget = max(bs, self.max_num_batched_tokens // bs * bs)       # whole blocks
+        budget = max(bs, (self.max_num_batched_tokens - used) // bs * bs)       # whole blocks
         end = seq.num_cached_tokens + budget
         seq.prefill_end = None if end >= len(seq) else end
 
-    def _schedule_prefill(self) -> list[Sequence]:
+    def _prompt_could_join(self, rows: int) -> bool:
+        """Mixed batches: is there a prompt (or the next chunk of one) that fits beside ``rows`` decode rows?  Checked
+        BEFORE the decode rows are scheduled (that step takes blocks); when the head of the queue only fits alone,
+        the step is the reference's: that prompt first, by itself."""
+        room = self.max_num_batched_tokens - rows
+        if self.prefilling is not None:
+            return room >= self.block_manager.block_size
+        if not self.waiting or rows >= self.max_num_seqs:
+            return False
+        head = self.waiting[0]
+        if not self.block_manager.can_allocate(head):
+            return False
+        if len(head) <= room:
+            return True
+        return self.chunked_prefill and len(head) > self.max_num_batched_tokens and room >= self.block_manager.block_size
+
+    def _schedule_prefill(self, used: int = 0) -> list[Sequence]:
+        """``used``: decode rows already in the step (mixed batches): they count against both budgets."""
         if self.prefilling is not None:                                 # the next chunk of the prompt in flight
-            self._next_chunk(self.prefilling)
+            self._next_chunk(self.prefilling, used)
             return [self.prefilling]
         batch: list[Sequence] = []
-        tokens = 0
+        tokens = used
         if (self.chunked_prefill and self.waiting and len(self.waiting[0]) > self.max_num_batched_tokens
                 and self.block_manager.can_allocate(self.waiting[0])):
             seq = self.waiting.popleft()
             self.block_manager.allocate(seq)                            # (prefix-cache hits shorten the first chunk)
             seq.status = SequenceStatus.RUNNING
             self.prefilling = seq
-            self._next_chunk(seq)
+            self._next_chunk(seq, used)
             return [seq]
-        while self.waiting and len(batch) < self.max_num_seqs:
+        while self.waiting and len(batch) + used < self.max_num_seqs:
             seq = self.waiting[0]
             # the budget test uses the full length; the charge below only the uncached part
             if tokens + len(seq) > self.max_num_batched_tokens or not self.block_manager.can_allocate(seq):
@@ -155,13 +190,15 @@ class Scheduler:
         self.waiting.appendleft(sequence)
 
     def postprocess(self, sequences: list[Sequence], token_ids: list[int]) -> None:
-        if self.prefilling is not None and sequences and sequences[0] is self.prefilling:
-            seq = self.prefilling
-            if seq.prefill_end is not None:          # a middle chunk: its KV is in the cache, its token is not a token
-                seq.num_cached_tokens = seq.prefill_end
-                return
-            self.prefilling = None                   # last chunk: from here on an ordinary running sequence
-            self.running.append(seq)
+        chunk = self.prefilling if any(s is self.prefilling for s in sequences) else None
+        if chunk is not None:
+            if chunk.prefill_end is not None:        # a middle chunk: its KV is in the cache, its token is not a token
+                chunk.num_cached_tokens = chunk.prefill_end
+                keep = [(s, t) for s, t in zip(sequences, token_ids, strict=True) if s is not chunk]
+                sequences, token_ids = [s for s, _ in keep], [t for _, t in keep]
+            else:
+                self.prefilling = None               # last chunk: from here on an ordinary running sequence
+                self.running.append(chunk)
         for seq, token in zip(sequences, token_ids, strict=True):
             seq.append_token(token)
             hit_eos = token == self.eos and not seq.ignore_eos

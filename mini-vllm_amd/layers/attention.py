@@ -56,6 +56,19 @@ class Attention(nn.Module):
             if ctx.cum_seqlens_q is None or ctx.cum_seqlens_k is None:
                 raise RuntimeError("Cumulative sequence lengths not set in context for prefill phase. "
                                    "This is a bug in the inference pipeline.")
+            if ctx.decode_rows and has_cache and ctx.block_tables is not None:
+                # mixed batch: the first rows are one-token continuations of cached sequences (the paged-decode
+                # kernel reads their K/V once, at HBM speed), the rest is prefill through the paged cache
+                nd = ctx.decode_rows
+                out = torch.empty_like(q)
+                hip_ops.paged_decode(q[:nd], self.k_cache, self.v_cache, ctx.block_tables[:nd], ctx.context_lens,
+                                     self.scale, out=out[:nd])
+                if q.shape[0] > nd:
+                    hip_ops.prefill_varlen(q[nd:], None, None, ctx.rest_cum_seqlens_q, ctx.rest_cum_seqlens_k,
+                                           ctx.rest_max_seqlen_q, ctx.rest_max_seqlen_k, self.scale,
+                                           k_cache=self.k_cache, v_cache=self.v_cache,
+                                           block_tables=ctx.block_tables[nd:], out=out[nd:])
+                return out
             if ctx.prefix_cached and has_cache and ctx.block_tables is not None:
                 # prefix-cache hit: the queries are the uncached suffix, the keys live in the cache
                 return hip_ops.prefill_varlen(q, None, None, ctx.cum_seqlens_q, ctx.cum_seqlens_k,

@@ -24,6 +24,15 @@ class Context:
     # build-only hint (not in the reference): some sequence of this prefill batch has a cached
     # prefix, so keys must be read from the paged cache instead of the contiguous k/v
     prefix_cached: bool = False
+    # build-only (mixed batches): the first ``decode_rows`` sequences of this prefill batch contribute ONE token each
+    # on top of a cached prefix — decode rows; attention serves them with the paged-decode kernel (their lengths in
+    # ``context_lens``, their tables the first rows of ``block_tables``) and the rest with the prefill kernel
+    # (``rest_*``: cumulative lengths re-based to the first non-decode sequence)
+    decode_rows: int = 0
+    rest_cum_seqlens_q: torch.Tensor | None = None
+    rest_cum_seqlens_k: torch.Tensor | None = None
+    rest_max_seqlen_q: int = 0
+    rest_max_seqlen_k: int = 0
 
 
 _CURRENT: ContextVar[Context | None] = ContextVar("minivllm_amd_context", default=None)
@@ -36,9 +45,11 @@ def get_context() -> Context:
 
 def set_context(is_prefill: bool, max_seqlen_q: int = 0, max_seqlen_k: int = 0,
                 cum_seqlens_q=None, cum_seqlens_k=None, slot_mapping=None, context_lens=None,
-                block_tables=None, prefix_cached: bool = False) -> None:
+                block_tables=None, prefix_cached: bool = False, decode_rows: int = 0, rest_cum_seqlens_q=None,
+                rest_cum_seqlens_k=None, rest_max_seqlen_q: int = 0, rest_max_seqlen_k: int = 0) -> None:
     _CURRENT.set(Context(is_prefill, max_seqlen_q, max_seqlen_k, cum_seqlens_q, cum_seqlens_k,
-                         slot_mapping, context_lens, block_tables, prefix_cached))
+                         slot_mapping, context_lens, block_tables, prefix_cached, decode_rows,
+                         rest_cum_seqlens_q, rest_cum_seqlens_k, rest_max_seqlen_q, rest_max_seqlen_k))
 
 
 def reset_context() -> None:

@@ -438,6 +438,57 @@ def test_chunked_prefill_equals_one_shot_prefill(golden_dir, tmp_path):
     torch.testing.assert_close(chunked[2][2][0], one_shot[0][2][0], rtol=2e-2, atol=2e-2)
 
 
+def test_mixed_batches_equal_separate_steps(golden_dir, tmp_path):
+    """SURVEY §8 f4, mixed prefill/decode batches: with enable_mixed_batches the running sequences decode inside the
+    prefill steps (paged-decode kernel for their rows, prefill kernel for the prompt chunk, one pass of the
+    projections for both).  Greedy continuations must equal those of the separate-step schedule, the mixed steps
+    must really have happened, and the decode rows' logits must match the pure decode step's."""
+    from safetensors.torch import save_file
+
+    from minivllm_amd import LLM, Config, SamplingParams
+
+    z = _load(golden_dir, "qwen3")
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    (d / "config.json").write_text(bytes(z["config_json"]).decode())
+    save_file({k[2:]: torch.from_numpy(z[k].view(np.int16).copy()).view(torch.bfloat16).contiguous()
+               for k in z.files if k.startswith("w:")}, str(d / "model.safetensors"))
+    g = torch.Generator().manual_seed(5)
+    prompts = [torch.randint(0, 320, (n,), generator=g).tolist() for n in (5, 40, 300, 70)]
+    sp = SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)
+    outs, steps = [], []
+    for mixed in (False, True):
+        cfg = Config(str(d), max_model_len=512, max_num_batched_tokens=130, max_num_seqs=8, num_kvcache_blocks=24,
+                     enforce_eager=True, dtype="bfloat16", enable_chunked_prefill=True, enable_mixed_batches=mixed)
+        engine = LLM(cfg)
+        ex = engine.model_runner.inference_executor
+        seen = []
+        real = ex.execute_batch
+
+        def spy(seqs, prefill=True, _r=real, _s=seen):
+            shape = [s.prefill_stop - s.num_cached_tokens for s in seqs] if prefill else [1] * len(seqs)
+            r = _r(seqs, prefill)
+            _s.append((prefill, shape, [s.seq_id for s in seqs], r[0].float().cpu()))
+            return r
+        ex.execute_batch = spy
+        outs.append([o["token_ids"] for o in engine.generate(prompts, sp, use_tqdm=False)])
+        steps.append(seen)
+        engine.exit()
+    assert outs[0] == outs[1]
+    plain = [x[1] for x in steps[0] if x[0]]
+    mixed = [x[1] for x in steps[1] if x[0]]
+    assert plain == [[5, 40], [128], [128], [44], [70]]               # separate steps: the chunks run alone
+    assert mixed == [[5, 40], [1, 1, 128], [1, 1, 128], [1, 1, 44], [1, 1, 1, 70]]
+    # the first sequence is done four steps earlier: it decoded inside the four mixed steps
+    last = [max(i for i, x in enumerate(st) if x[2][0] == st[0][2][0]) for st in steps]
+    assert last[1] == last[0] - 4
+    # the decode rows of the first mixed step against the first pure decode step of the other schedule (same rows)
+    first_mixed = next(x for x in steps[1] if x[0] and x[1][0] == 1)
+    first_decode = next(x for x in steps[0] if not x[0])
+    scale = float(first_decode[3].abs().max())
+    torch.testing.assert_close(first_mixed[3][:2], first_decode[3][:2], rtol=0, atol=2e-2 * scale)
+
+
 def test_kv_pool_sized_by_hbm_not_by_the_cap(tmp_path):
     """a10 on the real part: num_kvcache_blocks=-1 with limits so large (max_num_seqs 512 x max_model_len 40960 =
     327 680 blocks = 2.2 TiB of Qwen3-1.7B KV) that the 288 GB of HBM, not the cap, decide.  The pool must fit the

@@ -305,6 +305,68 @@ def test_chunked_prefill_schedule_and_inputs():
         s2.schedule()
 
 
+def test_mixed_batches_schedule_and_inputs():
+    """enable_mixed_batches (beyond the reference, §8 f4): while a 300-token prompt is prefilled in chunks, the two
+    running sequences keep decoding — every prefill step carries one token of each of them, in front, as rows whose
+    all-but-last tokens are cached; the builder names them decode rows (context lengths + their table rows) and
+    re-bases the prompt's cumulative lengths; middle chunks yield no token."""
+    cfg = SimpleNamespace(max_num_seqs=8, max_num_batched_tokens=130, eos=-1, num_kvcache_blocks=16,
+                          kvcache_block_size=64, max_model_len=512, enable_chunked_prefill=True,
+                          enable_mixed_batches=True)
+    sched = Scheduler(cfg)
+    builder = InputBuilder(64, 8, 512, 130)
+    sp = SamplingParams(max_tokens=20, ignore_eos=True)
+    a = Sequence(list(range(10, 73)), sp, block_size=64)      # 63 tokens: crosses a block edge while decoding
+    b = Sequence([5, 6, 7], sp, block_size=64)
+    sched.add(a)
+    sched.add(b)
+    batch, is_prefill = sched.schedule()                      # nothing is running yet: the reference's prefill
+    assert is_prefill and batch == [a, b]
+    assert builder.prefill(batch).decode_rows == 0
+    sched.postprocess(batch, [100, 200])
+    long_seq = Sequence(list(range(1000, 1300)), SamplingParams(max_tokens=3, ignore_eos=True), block_size=64)
+    sched.add(long_seq)
+    spans, next_tok = [], 300
+    while sched.prefilling is not None or long_seq.num_completion_tokens == 0:
+        la, lb = len(a), len(b)
+        batch, is_prefill = sched.schedule()
+        assert is_prefill and batch == [a, b, long_seq]
+        inp = builder.prefill(batch)
+        lo, hi = long_seq.num_cached_tokens, long_seq.prefill_stop
+        spans.append((lo, hi))
+        assert inp.decode_rows == 2 and inp.context_lens.tolist() == [la, lb]
+        assert inp.input_ids.tolist() == [a.last_token, b.last_token] + list(range(1000 + lo, 1000 + hi))
+        assert inp.positions.tolist() == [la - 1, lb - 1] + list(range(lo, hi))
+        assert inp.cum_seqlens_q.tolist() == [0, 1, 2, 2 + hi - lo] and inp.cum_seqlens_k.tolist() == [0, la, la + lb, la + lb + hi]
+        assert inp.rest_cum_seqlens_q.tolist() == [0, hi - lo] and inp.rest_cum_seqlens_k.tolist() == [0, hi]
+        assert (inp.rest_max_seqlen_q, inp.rest_max_seqlen_k) == (hi - lo, hi)
+        slot = lambda s, p: s.block_table[p // 64] * 64 + p % 64   # noqa: E731
+        assert inp.slot_mapping.tolist() == [slot(a, la - 1), slot(b, lb - 1)] + [slot(long_seq, p) for p in range(lo, hi)]
+        assert inp.block_tables[:2].tolist() == [a.block_table + [-1] * (inp.block_tables.shape[1] - len(a.block_table)),
+                                                 b.block_table + [-1] * (inp.block_tables.shape[1] - len(b.block_table))]
+        sched.postprocess(batch, [next_tok, next_tok + 1, next_tok + 2])
+        assert len(a) == la + 1 and len(b) == lb + 1 and a.last_token == next_tok and b.last_token == next_tok + 1
+        next_tok += 3
+    # 130-token budget minus two decode rows = 128 -> whole blocks: 128 / 128 / 44
+    assert spans == [(0, 128), (128, 256), (256, 300)]
+    assert len(long_seq) == 301 and long_seq.last_token == next_tok - 1 and sched.prefilling is None
+    assert list(sched.running) == [a, b, long_seq]
+    assert len(a.block_table) == 2                            # a grew past its first block during the mixed steps
+    batch, is_prefill = sched.schedule()                      # no prompt left: an ordinary decode step
+    assert not is_prefill and batch == [a, b, long_seq]
+    # a prompt that only fits the step alone is prefilled alone first (the reference's order), not starved
+    cfg2 = SimpleNamespace(max_num_seqs=8, max_num_batched_tokens=64, eos=-1, num_kvcache_blocks=16,
+                           kvcache_block_size=64, max_model_len=512, enable_mixed_batches=True)
+    s2 = Scheduler(cfg2)
+    r = Sequence([1, 2, 3], sp, block_size=64)
+    s2.add(r)
+    s2.postprocess(s2.schedule()[0], [9])
+    full = Sequence(list(range(64)), sp, block_size=64)       # 64 tokens + 1 decode row > 64
+    s2.add(full)
+    batch, is_prefill = s2.schedule()
+    assert is_prefill and batch == [full]
+
+
 def test_chunked_prefill_config_gate(tmp_path):
     from minivllm_amd.config import Config
 
