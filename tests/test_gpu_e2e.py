@@ -571,10 +571,11 @@ def test_randomized_serving_speculation_changes_nothing(golden_dir, tmp_path, mo
                                             max_tokens=rng.choice((1, 2, 7, 20, 33, 70)),
                                             ignore_eos=(i % 4 != 0)), rng.randrange(0, 60)))
 
-    def serve(eager, speculate):
+    def serve(eager, speculate, mixed=False):
         monkeypatch.setenv("MV_DECODE_SPECULATE", "1" if speculate else "0")
-        cfg = Config(str(d), max_model_len=512, max_num_batched_tokens=512, max_num_seqs=8, enforce_eager=eager,
-                     dtype="bfloat16", num_kvcache_blocks=14, load_format="dummy", seed=0)
+        cfg = Config(str(d), max_model_len=512, max_num_batched_tokens=128 if mixed else 512, max_num_seqs=8,
+                     enforce_eager=eager, dtype="bfloat16", num_kvcache_blocks=14, load_format="dummy", seed=0,
+                     enable_chunked_prefill=mixed, enable_mixed_batches=mixed)
         engine = LLM(cfg)
         engine.model_runner.model_manager.model.load_weights(weights)
         engine.scheduler.eos = 17
@@ -591,7 +592,7 @@ def test_randomized_serving_speculation_changes_nothing(golden_dir, tmp_path, mo
             step += 1
             assert step < 5000
         ex = engine.model_runner.inference_executor
-        stats = (ex.spec_hits, ex.spec_misses, engine.scheduler.num_preemptions)
+        stats = (ex.spec_hits, ex.spec_misses, engine.scheduler.num_preemptions, step)
         engine.exit()
         return [done[i] for i in range(len(reqs))], stats
 
@@ -609,3 +610,13 @@ def test_randomized_serving_speculation_changes_nothing(golden_dir, tmp_path, mo
     # can move a logit by an ulp, and a sampled row sitting on a probability edge then draws another token and
     # diverges for good — a slack of 2 requests for that, no more (a real regression loses most of them)
     assert agree >= len(reqs) - 2
+    # mixed prefill/decode batches + chunked prefill with a 128-token step budget (graphs on): another schedule
+    # altogether (decode rows ride in the prefill steps, 170-token prompts come in two chunks), so sampled rows draw
+    # from other Philox steps — the greedy requests must still say the same thing
+    mixed, st3 = serve(eager=False, speculate=True, mixed=True)
+    greedy = [i for i, r in enumerate(reqs) if r[1].temperature == 0.0]
+    agree_mixed = sum(mixed[i] == plain[i] for i in greedy)
+    print(f"mixed batches vs separate steps: {agree_mixed} of {len(greedy)} greedy requests identical; "
+          f"{st3[3]} engine steps against {st1[3]}, {st3[2]} preemptions")
+    assert all(len(mixed[i]) == len(plain[i]) for i in greedy)
+    assert agree_mixed >= len(greedy) - 2
