@@ -309,6 +309,40 @@ def test_prefill_varlen_vs_oracle(H, case, dtype):
     torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_prefill_mfma_every_workgroup_shape(H, variant, dtype):
+    """The flash prefill kernel in both of its workgroup shapes (flags >> 4: 1 = 4 waves x 32 rows, 2 = 8 waves x 32
+    rows; the default picks by prompt length), on lengths around every tile / row-block edge, contiguous and paged
+    (prefix-cached) K/V."""
+    Hq, Hkv, D = 8, 4, 128
+    lens = [300, 1000, 129, 128, 127, 63, 65, 257, 1, 2049]
+    T = sum(lens)
+    q = _randn(T, Hq, D, dtype=dtype, seed=40)
+    k = _randn(T, Hkv, D, dtype=dtype, seed=41)
+    v = _randn(T, Hkv, D, dtype=dtype, seed=42)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    scale = D ** -0.5
+    ref = O.prefill_varlen(q, k, v, cu, cu, scale)
+    out = H.prefill_varlen(q.to(DEV), k.to(DEV), v.to(DEV), cu.to(DEV), cu.to(DEV), max(lens), max(lens), scale,
+                           flags=variant << 4)
+    torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
+    # paged: the keys of each sequence live in the cache, the queries are the last third of it
+    bs = 64
+    kc, vc, table = _make_paged(3, Hkv, D, bs, [700, 131, 2300], dtype, seed=43)
+    ks = [700, 131, 2300]
+    qs = [233, 131, 767]
+    qn = _randn(sum(qs), Hq, D, dtype=dtype, seed=44)
+    cuq = torch.tensor([0] + list(torch.tensor(qs).cumsum(0)), dtype=torch.int32)
+    cuk = torch.tensor([0] + list(torch.tensor(ks).cumsum(0)), dtype=torch.int32)
+    kflat = torch.cat([torch.stack([kc[table[b, t // bs], t % bs] for t in range(n)]) for b, n in enumerate(ks)])
+    vflat = torch.cat([torch.stack([vc[table[b, t // bs], t % bs] for t in range(n)]) for b, n in enumerate(ks)])
+    ref2 = O.prefill_varlen(qn, kflat, vflat, cuq, cuk, scale)
+    out2 = H.prefill_varlen(qn.to(DEV), None, None, cuq.to(DEV), cuk.to(DEV), max(qs), max(ks), scale,
+                            k_cache=kc.to(DEV), v_cache=vc.to(DEV), block_tables=table.to(DEV), flags=variant << 4)
+    torch.testing.assert_close(out2.float().cpu(), ref2, **_tol(dtype))
+
+
 def test_prefill_mfma_strided_qkv_and_f16(H):
     """q/k/v as views of one fused qkv buffer (the engine's layout), f16, and a rescale-forcing
     input: one key per row with a huge score late in the sequence (online-softmax max jump)."""
