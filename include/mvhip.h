@@ -41,7 +41,8 @@ enum {
   MV_E_DTYPE = -3,     /* unknown dtype                                    */
   MV_E_WORKSPACE = -4, /* workspace too small                              */
   MV_E_ALIGN = -5,     /* pointer or stride not aligned for 16-byte access */
-  MV_E_RANGE = -6      /* scalar argument out of range                     */
+  MV_E_RANGE = -6,     /* scalar argument out of range                     */
+  MV_E_ALIAS = -7      /* an output overlaps an input other workgroups still read */
 };
 
 int mv_version(void);

@@ -12,6 +12,7 @@ extern "C" const char *mv_strerror(int code) {
     case MV_E_WORKSPACE: return "workspace too small or misaligned";
     case MV_E_ALIGN: return "pointer or stride not 16-byte aligned";
     case MV_E_RANGE: return "scalar argument out of range";
+    case MV_E_ALIAS: return "an output buffer aliases an input that is still being read";
     default: break;
   }
   if (code > 0) return hipGetErrorString((hipError_t)code);

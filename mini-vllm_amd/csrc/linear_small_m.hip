@@ -561,7 +561,7 @@ static int norm_check(const void *x, int64_t x_stride, const void *residual, int
   if (!mv_aligned16(norm_w) || (residual && (!mv_aligned16(residual) || !mv_aligned16(residual_out) ||
                                              (res_stride & 7) || (res_out_stride & 7))))
     return MV_E_ALIGN;
-  if (residual && residual_out == residual) return MV_E_ALIGN;  // the other workgroups still read the old rows
+  if (residual && residual_out == residual) return MV_E_ALIAS;  // the other workgroups still read the old rows
   return MV_OK;
 }
 

@@ -628,6 +628,29 @@ def test_norm_folded_into_the_small_m_projection_is_bit_identical(H, dtype, m, n
         assert ok, worst
 
 
+def test_norm_folding_refuses_an_aliased_residual(H):
+    """The new residual is written by ONE workgroup while the others still read the old one: the C entry point refuses
+    residual_out == residual instead of racing."""
+    import ctypes
+
+    dtype = torch.bfloat16
+    x = torch.ones(2, 256, dtype=dtype, device=DEV)
+    res = torch.ones(2, 256, dtype=dtype, device=DEV)
+    nw = torch.ones(256, dtype=dtype, device=DEV)
+    w = torch.zeros(64, 256, dtype=dtype, device=DEV)
+    wp = H.pack_weight(w)
+    out = torch.empty(2, 64, dtype=dtype, device=DEV)
+    lib = H._lib
+    rc = lib.mv_norm_linear_small_m_packed(x.data_ptr(), 256, res.data_ptr(), 256, res.data_ptr(), 256, nw.data_ptr(),
+                                           ctypes.c_float(1e-6), wp.data_ptr(), None, out.data_ptr(), 64, 2, 64, 256,
+                                           0, 0, None)
+    assert rc == -7 and b"alias" in lib.mv_strerror(rc).lower()
+    rc = lib.mv_norm_linear_small_m_packed(x.data_ptr(), 256, res.data_ptr(), 256, None, 0, nw.data_ptr(),
+                                           ctypes.c_float(1e-6), wp.data_ptr(), None, out.data_ptr(), 64, 2, 64, 256,
+                                           0, 0, None)
+    assert rc < 0                                    # a residual without a place for the new one
+
+
 def test_norm_folding_declines_what_it_cannot_hold(H):
     dtype = torch.bfloat16
     w = torch.zeros(256, 3584, dtype=dtype, device=DEV)
