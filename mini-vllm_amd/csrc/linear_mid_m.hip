@@ -330,6 +330,15 @@ constexpr Cfg kCfgs[] = {
     {256, 128, 4, 2, 2, 2, 3, 4, true},    // 8: 160 KB
     {128, 48, 4, 1, 2, 1, 5, 12, false},   // 9: 152 KB
     {64, 64, 2, 2, 1, 1, 8, 9, true},      // 10: 136 KB
+    {64, 64, 2, 2, 2, 2, 8, 9, true},      // 11: tile 10 with two loader waves per operand (a DMA instruction
+    {64, 64, 2, 2, 2, 1, 8, 9, true},      // 12:   costs its wave ~64 issue cycles: one loader caps at ~16 B/clk)
+    {128, 96, 4, 1, 4, 2, 4, 7, true},     // 13: tile 1 with four x loaders
+    {128, 96, 4, 1, 4, 3, 4, 7, true},     // 14: ... and three W loaders
+    {64, 64, 2, 2, 4, 4, 8, 9, true},      // 15
+    {128, 96, 4, 1, 8, 3, 4, 7, true},     // 16
+    {128, 128, 4, 2, 4, 4, 4, 5, true},    // 17: tile 6 with 4 + 4 loaders
+    {256, 160, 8, 1, 4, 4, 3, 3, true},    // 18: tile 7 with 4 + 4 loaders
+    {256, 128, 4, 2, 4, 4, 3, 4, true},    // 19: tile 8 with 4 + 4 loaders
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -370,6 +379,15 @@ int launch_cfg(MidParams p, int cfg, int splits, hipStream_t st) {
     case 8: return launch_one<Tag, 256, 128, 4, 2, 2, 2, 3, 4, 1, EPI>(p, splits, st);
     case 9: if constexpr (!G) return launch_one<Tag, 128, 48, 4, 1, 2, 1, 5, 12, 1, EPI>(p, splits, st); else break;
     case 10: return launch_one<Tag, 64, 64, 2, 2, 1, 1, 8, 9, 1, EPI>(p, splits, st);
+    case 11: return launch_one<Tag, 64, 64, 2, 2, 2, 2, 8, 9, 1, EPI>(p, splits, st);
+    case 12: return launch_one<Tag, 64, 64, 2, 2, 2, 1, 8, 9, 1, EPI>(p, splits, st);
+    case 13: return launch_one<Tag, 128, 96, 4, 1, 4, 2, 4, 7, 1, EPI>(p, splits, st);
+    case 14: return launch_one<Tag, 128, 96, 4, 1, 4, 3, 4, 7, 1, EPI>(p, splits, st);
+    case 15: return launch_one<Tag, 64, 64, 2, 2, 4, 4, 8, 9, 1, EPI>(p, splits, st);
+    case 16: return launch_one<Tag, 128, 96, 4, 1, 8, 3, 4, 7, 1, EPI>(p, splits, st);
+    case 17: return launch_one<Tag, 128, 128, 4, 2, 4, 4, 4, 5, 1, EPI>(p, splits, st);
+    case 18: return launch_one<Tag, 256, 160, 8, 1, 4, 4, 3, 3, 0, EPI>(p, splits, st);
+    case 19: return launch_one<Tag, 256, 128, 4, 2, 4, 4, 3, 4, 1, EPI>(p, splits, st);
     default: break;
   }
   return MV_E_RANGE;

@@ -52,8 +52,11 @@ def small_m(x, weight) -> bool:
 MID_M_MAX = int(os.environ.get("MV_LINEAR_MID_M_MAX", "512"))   # 0 disables (everything above small-M on the library)
 # workgroup tiles of mv_linear_mid_m (ids of the table in csrc/linear_mid_m.hip): id -> (BM, BN, takes the gated form)
 MID_CFGS = {1: (128, 96, True), 2: (256, 48, False), 3: (128, 32, True), 4: (64, 32, False), 5: (256, 64, True),
-            6: (128, 128, True), 7: (256, 160, True), 8: (256, 128, True), 9: (128, 48, False), 10: (64, 64, True)}
-_TUNED_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tuned", "mid_m_gfx950.json")
+            6: (128, 128, True), 7: (256, 160, True), 8: (256, 128, True), 9: (128, 48, False), 10: (64, 64, True),
+            11: (64, 64, True), 12: (64, 64, True), 13: (128, 96, True), 14: (128, 96, True), 15: (64, 64, True),
+            16: (128, 96, True), 17: (128, 128, True), 18: (256, 160, True), 19: (256, 128, True)}
+_TUNED_PATH = os.environ.get("MV_MID_TUNED") or os.path.join(
+    os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tuned", "mid_m_gfx950.json")
 _TUNED_MS = (64, 128, 192, 256, 384, 512)
 try:
     with open(_TUNED_PATH) as _f:
