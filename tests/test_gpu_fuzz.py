@@ -1,0 +1,112 @@
+"""Seeded random-shape sweeps of the round-2 kernels against the oracle (C-ABI through hip_ops): head layouts, block
+sizes, ragged contexts and holes for the paged-decode kernels (both mappings of the vector kernel, the matrix-core
+kernel); row counts, ragged N and K for the small-M projections on row-major and fragment-packed weights and their
+norm-folded forms.  Sizes are kept small enough for the CPU oracle; every case is reproducible from its seed."""
+import math
+import random
+
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def H():
+    from minivllm_amd import hip_ops
+    return hip_ops
+
+
+def _tol(dtype):
+    return {torch.float32: dict(rtol=1e-4, atol=1e-5), torch.bfloat16: dict(rtol=2 ** -7, atol=2 ** -7),
+            torch.float16: dict(rtol=2 ** -10, atol=2 ** -9)}[dtype]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_paged_decode_random_layouts(H, seed):
+    rng = random.Random(1000 + seed)
+    g = torch.Generator().manual_seed(seed)
+    dtype = rng.choice([torch.bfloat16, torch.float16, torch.float32])
+    D = rng.choice([64, 128])
+    hkv = rng.choice([1, 2, 4, 8])
+    grp = rng.choice([1, 2, 3, 4, 7, 8])
+    bs = rng.choice([4, 16, 32, 64, 128])
+    B = rng.randint(1, 6)
+    ctxs = [rng.choice([1, 2, bs - 1, bs, bs + 1, 3 * bs + 5, rng.randint(1, 900)]) for _ in range(B)]
+    ctxs = [max(1, c) for c in ctxs]
+    nblk = [-(-c // bs) for c in ctxs]
+    width = max(nblk) + rng.randint(0, 2)
+    nb = sum(nblk) + 3
+    perm = torch.randperm(nb, generator=g).tolist()
+    table = torch.full((B, width), -1, dtype=torch.int32)
+    it = iter(perm)
+    for b in range(B):
+        for j in range(nblk[b]):
+            table[b, j] = next(it)
+    if rng.random() < 0.4:                                     # a hole inside some context (contributes nothing)
+        b = rng.randrange(B)
+        if nblk[b] > 1:
+            table[b, rng.randrange(nblk[b])] = -1
+    kc = torch.randn(nb, bs, hkv, D, generator=g).to(dtype)
+    vc = torch.randn(nb, bs, hkv, D, generator=g).to(dtype)
+    q = torch.randn(B, hkv * grp, D, generator=g).to(dtype)
+    ctx = torch.tensor(ctxs, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(D)
+    ref = O.paged_decode(q, kc, vc, table, ctx, scale)
+    args = (q.to(DEV), kc.to(DEV), vc.to(DEV), table.to(DEV), ctx.to(DEV), scale)
+    for flags in (0, H.MV_DECODE_PER_HEAD, H.MV_DECODE_VECTOR):
+        out = H.paged_decode(*args, flags=flags)
+        torch.testing.assert_close(out.float().cpu(), ref, msg=lambda m: f"seed {seed} flags {flags} {dtype} D={D} "
+                                   f"hkv={hkv} g={grp} bs={bs} ctx={ctxs}: {m}", **_tol(dtype))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_small_m_projections_random_shapes(H, seed):
+    rng = random.Random(2000 + seed)
+    g = torch.Generator().manual_seed(seed)
+    dtype = rng.choice([torch.bfloat16, torch.float16])
+    m = rng.choice([1, 2, 3, 4, 5, 8, 13, 16])
+    k = 64 * rng.randint(4, 60)
+    n = 4 * rng.randint(4, 700)
+    x = torch.randn(m, k, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(dtype).to(DEV)
+    b = torch.randn(n, generator=g).to(dtype).to(DEV) if rng.random() < 0.5 else None
+    exact = O.linear(x.cpu(), w.cpu(), None if b is None else b.cpu())
+    eps = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    bound = eps * exact.abs() + eps * exact.abs().mean()
+    wp = H.pack_weight(w)
+    for got in (H.linear_small_m(x, w, b), H.linear_small_m(x, w, b, packed=wp)):
+        assert ((got.double().cpu() - exact).abs() <= bound).all(), (seed, m, n, k)
+    # the norm-folded form where it takes the shape: bit-identical to norm, then projection
+    if H.norm_linear_small_m_ok(x, n, wp):
+        nw = (1.0 + 0.1 * torch.randn(k, generator=g)).to(dtype).to(DEV)
+        res = torch.randn(m, k, generator=g).to(dtype).to(DEV)
+        h_ref, r_ref = H.add_rmsnorm(x, res, nw, 1e-6, inplace=False)
+        out, r_out = H.norm_linear_small_m(x, res, nw, 1e-6, wp, n, b)
+        assert torch.equal(out, H.linear_small_m(h_ref, w, b, packed=wp)) and torch.equal(r_out, r_ref), (seed, m, n, k)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_gated_small_m_random_shapes(H, seed):
+    rng = random.Random(3000 + seed)
+    g = torch.Generator().manual_seed(seed)
+    dtype = rng.choice([torch.bfloat16, torch.float16])
+    m = rng.choice([1, 2, 4, 7, 16])
+    k = 64 * rng.randint(4, 40)
+    inter = 16 * rng.randint(2, 300)
+    x = torch.randn(m, k, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(2 * inter, k, generator=g) * k ** -0.5).to(dtype).to(DEV)
+    wp = H.pack_weight(w)
+    want = O.gate_up_silu(x.cpu(), w.cpu(), dtype).double()
+    eps = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    bound = 4.0 * eps * want.abs() + eps * want.abs().mean()
+    for got in (H.gate_up_silu_small_m(x, w), H.gate_up_silu_small_m(x, w, packed=wp)):
+        assert ((got.double().cpu() - want).abs() <= bound).all(), (seed, m, inter, k)
+    if H.norm_linear_small_m_ok(x, 2 * inter, wp):
+        nw = (1.0 + 0.1 * torch.randn(k, generator=g)).to(dtype).to(DEV)
+        h_ref = H.rmsnorm(x, nw, 1e-6)
+        out, r_out = H.norm_linear_small_m(x, None, nw, 1e-6, wp, inter, None, gated=True)
+        assert torch.equal(out, H.gate_up_silu_small_m(h_ref, w, packed=wp)) and r_out.data_ptr() == x.data_ptr()
