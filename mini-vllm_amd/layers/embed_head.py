@@ -9,7 +9,7 @@ from ..parallel_state import (get_tensor_parallel_rank, get_tensor_parallel_worl
                               tp_all_gather_last_dim, tp_all_reduce)
 from ..utils.context import get_context
 from .. import hip_ops
-from .linear import linear, small_m
+from .linear import linear, mid_m, small_m, tuned_plan
 
 __all__ = ["VocabParallelEmbedding", "ParallelLMHead", "get_tensor_parallel_rank",
            "get_tensor_parallel_world_size"]
@@ -68,8 +68,15 @@ class ParallelLMHead(VocabParallelEmbedding):
         ctx = get_context()
         if ctx.is_prefill:  # only each sequence's last token is sampled
             x = x[(ctx.cum_seqlens_q[1:] - 1).long()].contiguous()
+        logits = None
         if small_m(x, self.weight):
             logits = hip_ops.linear_small_m(x, self.weight, packed=self.weight_packed)
-        else:   # (decode batches above the small-M range: the library GEMM measured faster than mv_linear_mid_m here)
+        elif mid_m(x, self.weight_packed) and hip_ops.linear_mid_m_ok(x, self.weight.shape[0]):
+            # decode batches: mv_linear_mid_m where it MEASURED faster than the library GEMM for this head
+            # (tuned/mid_m_gfx950.json: Qwen3-1.7B at 256 rows 184 vs 200 us, Qwen2-7B 307 vs 332 us)
+            plan = tuned_plan("col", x.numel() // x.shape[-1], self.weight.shape[0], self.weight.shape[1])
+            if plan is not None and plan[0]:
+                logits = hip_ops.linear_mid_m(x, self.weight_packed, self.weight.shape[0], None, plan[0])
+        if logits is None:
             logits = linear(x, self.weight)
         return tp_all_gather_last_dim(logits) if self.tp_size > 1 and gather else logits

@@ -26,7 +26,8 @@ from ..parallel_state import (divide, get_tensor_parallel_rank, get_tensor_paral
 from ..utils.loader import materialize
 
 __all__ = ["LinearBase", "ReplicatedLinear", "ColumnParallelLinear", "MergedColumnParallelLinear",
-           "QKVParallelLinear", "RowParallelLinear", "divide", "linear", "small_m", "PartialSum", "mid_plan"]
+           "QKVParallelLinear", "RowParallelLinear", "divide", "linear", "small_m", "PartialSum", "mid_plan",
+           "tuned_plan", "mid_m"]
 
 # rows up to which the weight-streaming kernel beats the library GEMM (tools/bench_linear.py); 0 disables
 SMALL_M_MAX = int(os.environ.get("MV_LINEAR_SMALL_M_MAX", "16"))
@@ -116,6 +117,14 @@ def mid_plan(kind: str, m: int, n: int, k: int):
             if t < best_t:
                 best, best_t = (cid, splits), t
     return best
+
+
+def tuned_plan(kind: str, m: int, n: int, k: int):
+    """The measured (cfg, splits) of this exact shape, or None when the table does not hold it (the LM head only
+    leaves the library GEMM on a measurement, never on the cost model)."""
+    mt = next((t for t in _TUNED_MS if t >= m), None)
+    hit = _TUNED.get(f"{kind}:{mt}:{n}:{k}") if mt else None
+    return None if hit is None else (int(hit["cfg"]), int(hit["splits"]))
 
 
 def mid_m(x, packed) -> bool:
