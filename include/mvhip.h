@@ -115,7 +115,7 @@ enum {
   MV_DECODE_KLDS_OFF = 4, /* matrix-core kernel: K straight to registers               */
   MV_DECODE_KLDS_ON = 8,  /* matrix-core kernel: K through LDS                         */
   MV_DECODE_PER_HEAD = 16 /* vector kernel: one kv head per workgroup (never whole-row loads)  */
-  /* bits 8-15, when non-zero: workgroups to aim for when splitting the context, in units of 64 (tuning aid) */
+  /* bits 8-15, when non-zero: workgroups to aim for when splitting the context, in units of 16 (tuning aid) */
 };
 size_t mv_paged_decode_workspace_bytes(int batch, int n_heads, int n_kv_heads,
                                        int head_dim, int block_size,

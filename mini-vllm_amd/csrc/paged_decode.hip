@@ -389,7 +389,7 @@ bool make_plan(int batch, int n_heads, int n_kv_heads, int head_dim, int block_s
   // whole-row loads: HBM likes FEWER concurrent streams (B = 256 x 1024 tokens: 162 us at 512 workgroups,
   // 170 us at 1024, 182 us at 2560; the per-head mapping: 171 us at its best)
   int target = pl->wide ? kTargetWorkgroups / 4 : (pl->mfma ? kTargetWorkgroups / 2 : kTargetWorkgroups);
-  if ((flags >> 8) & 0xff) target = ((flags >> 8) & 0xff) * 64;  // tuning aid: bits 8-15 = target workgroups / 64
+  if ((flags >> 8) & 0xff) target = ((flags >> 8) & 0xff) * 16;  // tuning aid: bits 8-15 = target workgroups / 16
   int ns = wg > 0 ? (int)((target + wg - 1) / wg) : 1;
   if (ns > max_units) ns = max_units;
   if (ns > kMaxSplits) ns = kMaxSplits;

@@ -108,7 +108,7 @@ MV_PREFILL_SIMPLE = 1
 def _decode_flags_from_env() -> int:
     """MV_DECODE_MFMA_MIN_G=1 / 99: matrix-core decode kernel always / never; MV_DECODE_MFMA_KLDS=0 / 1: K straight
     to registers / through LDS; MV_DECODE_PER_HEAD=1: vector kernel with one kv head per workgroup;
-    MV_DECODE_TARGET_WGS=n: workgroups the context split aims for (multiple of 64).
+    MV_DECODE_TARGET_WGS=n: workgroups the context split aims for (multiple of 16).
     (Bench and debugging aids; unset = the kernels choose from the shape.)"""
     f = 0
     g = os.environ.get("MV_DECODE_MFMA_MIN_G")
@@ -121,7 +121,7 @@ def _decode_flags_from_env() -> int:
         f |= MV_DECODE_PER_HEAD
     t = os.environ.get("MV_DECODE_TARGET_WGS")
     if t is not None:
-        f |= (max(1, min(255, int(t) // 64))) << 8
+        f |= (max(1, min(255, int(t) // 16))) << 8
     return f
 
 

@@ -81,7 +81,7 @@ if __name__ == "__main__":
             bench_decode(256, 16, 8, 128, 1024)
         print("--- (warm-up above) ---")
         for rep in range(3):
-            # flag 16 = one kv head per workgroup (the round-1 mapping); bits 8-15 = context-split target / 64
+            # flag 16 = one kv head per workgroup (the round-1 mapping); bits 8-15 = context-split target / 16
             # (round 2: an XCD-aware grid order was tried here: 172 -> 173 us, dropped)
             for fl in (16, 0):
                 bench_decode(256, 16, 8, 128, 1024, flags=fl)
