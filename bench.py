@@ -120,7 +120,7 @@ def decode_roofline(engine, args):
     """Average duration of the paged-decode launches of REAL decode steps of this run, measured with
     HIP events on the launching stream: the executor is switched to eager for a few extra steps and
     every mv_paged_decode launch (one per layer, in situ between the GEMMs, on the live block
-    tables / context lengths / KV cache) is bracketed by an event pair."""
+    tables / context lengths / KV cache) is bracketed by an event pair; the host runs ahead of the GPU (see below)."""
     from minivllm_amd import hip_ops
     from minivllm_amd.layers import attention as attn_mod
 
@@ -142,6 +142,11 @@ def decode_roofline(engine, args):
         return out
     was_eager = ex.enforce_eager
     ex.enforce_eager = True
+    # (Events cannot be recorded inside a captured graph on ROCm — "External events are disallowed in rocm",
+    # tools/dbg/ext_event_probe.py — so the probe steps are eager.  Keeping the host ahead of the GPU with a spin
+    # kernel in front of each probe step changes nothing (180 vs 178 us): what an event pair adds to the ~168 us
+    # rocprofv3 sees for this kernel inside the graph is the two event packets themselves, reported below as
+    # `event_pair_floor_us` = the same pair around a one-element fill.)
     try:
         engine.step()                       # eager warm-up step (kernels already resident)
         attn_mod.hip_ops.paged_decode = timed
@@ -154,6 +159,18 @@ def decode_roofline(engine, args):
     torch.cuda.synchronize()
     assert len(pairs) == probe_steps * L
     times = [a.elapsed_time(b) for a, b in pairs]
+    # what the event pair itself costs: the same bracket around a one-element fill, inside a stream that is busy
+    tiny, floor = torch.zeros(1, device=ex.device), []
+    busy = torch.empty(256 << 20, dtype=torch.uint8, device=ex.device)
+    for _ in range(20):
+        busy.zero_()                        # ~50 us of work ahead of the pair: the host is not what it times
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tiny.zero_()
+        e1.record()
+        floor.append((e0, e1))
+    torch.cuda.synchronize()
+    floor_us = sorted(a.elapsed_time(b) for a, b in floor)[len(floor) // 2] * 1e3
     # an event pair also spans whatever the HOST does between recording the first event and enqueuing the
     # kernel while the GPU is idle (eager probe steps are launch-bound): a rare host stall there (seen: one
     # ~170 ms gap in 84 launches) is not kernel time.  Launches above 3x the median are left out and counted.
@@ -179,7 +196,8 @@ def decode_roofline(engine, args):
     return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_source": "profiles/r02_pmc_decode.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes on this kernel and head layout at B=256 ctx=1024, per launch, scaled to this run's context; counters cannot be read inside a timed run)" if traffic else None,
-            "bytes_per_launch": algo, "us_per_launch": round(sec * 1e6, 2), "launches_timed": len(kept),
+            "bytes_per_launch": algo, "us_per_launch": round(sec * 1e6, 2), "event_pair_floor_us": round(floor_us, 2),
+            "launches_timed": len(kept),
             "launches_discarded_host_stall": len(times) - len(kept)}
 
 
