@@ -107,11 +107,11 @@ class Sequence:
         payload = self.token_ids if self.num_completion_tokens == 0 else self.last_token
         return (self.num_tokens, self.num_prompt_tokens, self.num_cached_tokens, self.block_table,
                 self.block_size, payload, self.temperature, self.top_p, self.top_k, self.min_p,
-                self.max_tokens, self.ignore_eos)
+                self.max_tokens, self.ignore_eos, self.prefill_end)
 
     def __setstate__(self, state) -> None:
         (self.num_tokens, self.num_prompt_tokens, self.num_cached_tokens, self.block_table,
-         self.block_size, payload, temperature, top_p, top_k, min_p, max_tokens, ignore_eos) = state
+         self.block_size, payload, temperature, top_p, top_k, min_p, max_tokens, ignore_eos, prefill_end) = state
         decoding = self.num_tokens - self.num_prompt_tokens > 0
         if isinstance(payload, int):
             if decoding:
@@ -124,6 +124,6 @@ class Sequence:
             self.token_ids = payload
             self.last_token = payload[-1] if payload else 0
         self.status = SequenceStatus.RUNNING if decoding else SequenceStatus.WAITING
-        self.prefill_end = None
+        self.prefill_end = prefill_end   # a chunk of a long prompt: the workers must compute the same token range
         self._adopt_sampling(SamplingParams(temperature=temperature, top_p=top_p, top_k=top_k,
                                             min_p=min_p, max_tokens=max_tokens, ignore_eos=ignore_eos))

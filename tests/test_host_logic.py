@@ -218,6 +218,18 @@ def test_sequence_block_math_and_pickle():
     r = pickle.loads(pickle.dumps(s))            # decode phase: only the last token travels
     assert r.last_token == 5 and len(r) == 131 and r.token_ids[-1] == 5 and r.token_ids[0] == 0
     assert r.block_table == [4, 2, 9] and r.status == SequenceStatus.RUNNING
+    # what a tensor-parallel worker rebuilds must give the input builder the same token ranges as rank 0's object:
+    # a chunk of a long prompt (prefill_end), and a decode row of a mixed batch (num_cached_tokens = len - 1)
+    from minivllm_amd.engine.input_builder import InputBuilder
+    c = Sequence(list(range(1, 301)), SamplingParams(max_tokens=3), block_size=64)
+    c.block_table, c.num_cached_tokens, c.prefill_end = [7, 8, 9, 10, 11], 128, 256
+    s.num_cached_tokens = len(s) - 1
+    mine = InputBuilder(64, 4, 512, 512).prefill([s, c])
+    theirs = InputBuilder(64, 4, 512, 512).prefill(pickle.loads(pickle.dumps([s, c])))
+    for name in ("input_ids", "positions", "cum_seqlens_q", "cum_seqlens_k", "slot_mapping", "block_tables",
+                 "context_lens", "rest_cum_seqlens_q", "rest_cum_seqlens_k"):
+        assert torch.equal(getattr(mine, name), getattr(theirs, name)), name
+    assert (mine.decode_rows, mine.max_seqlen_q, mine.rest_max_seqlen_k) == (theirs.decode_rows, theirs.max_seqlen_q, theirs.rest_max_seqlen_k) == (1, 128, 256)
     s.status = SequenceStatus.FINISHED
     with pytest.raises(RuntimeError):
         s.append_token(1)

@@ -459,7 +459,7 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
     kw = dict(max_model_len=512, max_num_batched_tokens=1024, max_num_seqs=8, num_kvcache_blocks=24,
               enforce_eager=True)
 
-    def run(tp, dtype, eager=True, sp=sp, **over):
+    def run(tp, dtype, eager=True, sp=sp, prompts=prompts, **over):
         llm = LLM(Config(str(d), dtype=dtype, tensor_parallel_size=tp, seed=3, **{**kw, "enforce_eager": eager, **over}))
         try:
             ex = llm.model_runner.inference_executor
@@ -481,6 +481,14 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
     # does not depend on the TP degree (fp32: the probabilities agree to ~1e-6)
     sampled = SamplingParams(temperature=0.8, top_p=0.95, top_k=50, max_tokens=12, ignore_eos=True)
     assert run(2, "float32", sp=sampled)[0] == run(1, "float32", sp=sampled)[0]
+    # chunked prefill + mixed batches under TP: the worker rebuilds the chunk boundaries and the decode rows from the
+    # pickled sequences (prefill_end, num_cached_tokens) — a rank that computed another token range would hang the
+    # all-reduce or mismatch; fp32 tokens equal TP = 1 on the same schedule and the one-shot schedule's
+    g5 = torch.Generator().manual_seed(5)
+    longer = [torch.randint(0, 320, (n,), generator=g5).tolist() for n in (5, 40, 300, 70)]
+    sched = dict(max_num_batched_tokens=130, enable_chunked_prefill=True, enable_mixed_batches=True)
+    t2 = run(2, "float32", prompts=longer, **sched)[0]
+    assert t2 == run(1, "float32", prompts=longer, **sched)[0] == run(1, "float32", prompts=longer)[0]
     # bf16 (all-reduces on the peer-to-peer kernel): same lengths, and the first tokens agree (later ones may
     # legitimately diverge after a near-tie, as between any two bf16 summation orders)
     (a, *_), (b, *_) = run(2, "bfloat16"), run(1, "bfloat16")
