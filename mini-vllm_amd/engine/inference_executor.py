@@ -187,6 +187,15 @@ class InferenceExecutor:
         for s in dummy:
             s.append_token(0)
         self.execute_batch(dummy, prefill=False)
+        # the library GEMM's one-time set-up (hipBLASLt handle, workspace, kernel database: ~170 ms) belongs here, not
+        # in the first real prefill step: with every decode-sized projection on the hand-written kernels nothing
+        # else would call it before that step
+        if self.device.type == "cuda":
+            for mod in self.model.modules():
+                w = getattr(mod, "weight", None)
+                if w is not None and w.dim() == 2 and hasattr(mod, "input_size"):   # a LinearBase projection
+                    torch.nn.functional.linear(torch.zeros(1024, w.shape[1], dtype=w.dtype, device=w.device), w)
+                    break
         torch.cuda.synchronize(self.device)
 
     # ------------------------------------------------------------------ one step
