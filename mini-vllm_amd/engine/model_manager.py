@@ -101,8 +101,17 @@ class ModelManager:
         # decode steps stream a fragment-ordered copy of every projection weight and of the LM head
         # (layers/linear.py); MV_PACK_WEIGHTS=0 keeps only the row-major weights (library GEMMs above 16-32 rows)
         if os.environ.get("MV_PACK_WEIGHTS", "1") != "0":
-            for mod in self.model.modules():
-                if hasattr(mod, "pack_for_decode"):
+            mods = [m for m in self.model.modules() if hasattr(m, "pack_for_decode")]
+            # the copies double the projection weights in HBM: only while they stay a modest share of the device
+            # (Qwen2-72B on ONE GPU: 135 GiB of weights — a second copy would leave no room for the KV pool; it then
+            # decodes on the row-major weights, like MV_PACK_WEIGHTS=0)
+            extra = sum(m.weight.numel() * m.weight.element_size() for m in mods)
+            total = torch.cuda.get_device_properties(self.device).total_memory if self.device.type == "cuda" else 0
+            if total and extra > 0.25 * total:
+                logger.warning("not packing the projection weights for decode: %.1f GiB of copies on a %.0f GiB device",
+                               extra / 2 ** 30, total / 2 ** 30)
+            else:
+                for mod in mods:
                     mod.pack_for_decode()
 
     @staticmethod
