@@ -110,7 +110,7 @@ def mid_plan(kind: str, m: int, n: int, k: int):
     for cid, (bm, bn, gated_ok) in MID_CFGS.items():
         if kind == "gated" and not gated_ok:
             continue
-        for splits in ((1, 2, 4) if kind == "row" else (1,)):
+        for splits in (((1, 2, 4, 8) if k >= 8192 else (1, 2, 4)) if kind == "row" else (1,)):
             if (k // 64) % splits:
                 continue
             t = _model_cost(m, n, k, bm, bn, kind == "gated", splits)

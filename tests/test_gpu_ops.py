@@ -740,7 +740,8 @@ def test_gate_up_silu_mid_m(H, dtype, m, inter, k):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("m,n,k,splits", [(256, 2048, 6144, 2), (256, 3584, 2048, 4), (100, 1000, 1024, 4), (64, 512, 192, 2)])
+@pytest.mark.parametrize("m,n,k,splits", [(256, 2048, 6144, 2), (256, 3584, 2048, 4), (100, 1000, 1024, 4), (64, 512, 192, 2),
+                                            (256, 3584, 9472, 8)])
 def test_split_k_partials_and_the_norm_behind_them(H, dtype, m, n, k, splits):
     x = _randn(m, k, dtype=dtype, seed=m).to(DEV)
     w = (_randn(n, k, dtype=torch.float32, seed=n) * k ** -0.5).to(dtype).to(DEV)
@@ -754,8 +755,10 @@ def test_split_k_partials_and_the_norm_behind_them(H, dtype, m, n, k, splits):
         assert (part.double().sum(0).cpu() - exact).abs().max() < 1e-4 * max(1.0, exact.abs().max())
         # the consumer: sum in split order, ONE rounding to dtype (the GEMM's), then add + norm exactly as
         # mv_add_rmsnorm does on that rounded tensor
-        y_ref, r_ref = H.add_rmsnorm(part.sum(0).to(dtype) if splits == 2 else
-                                     (((part[0] + part[1]) + part[2]) + part[3]).to(dtype), res.clone(), nw, 1e-6)
+        acc = part[0]
+        for i in range(1, splits):
+            acc = acc + part[i]                 # split order, fp32
+        y_ref, r_ref = H.add_rmsnorm(acc.to(dtype), res.clone(), nw, 1e-6)
         y, r = H.add_rmsnorm_partial(part, res.clone(), nw, 1e-6)
         assert torch.equal(r, r_ref)          # the summed, rounded projection + residual: bit-exact
         # the normed output: same formula on the same values in another instantiation of the kernel template;

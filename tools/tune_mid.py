@@ -32,6 +32,7 @@ SHAPES = {
                  ("row", 3584, 18944, False)],
     "lm-heads": [("col", 151936, 1024, False), ("col", 151936, 2048, False), ("col", 152064, 3584, False),
                  ("col", 19008, 8192, False)],
+    "deep-k": [("row", 3584, 18944, False), ("row", 8192, 29568, False), ("row", 8192, 8192, False)],
     "qwen2-72b-tp8": [("col", 1280, 8192, True), ("row", 8192, 1024, False), ("gated", 3696, 8192, False)],
     "qwen2-72b": [("col", 10240, 8192, True), ("row", 8192, 8192, False), ("gated", 29568, 8192, False),
                   ("row", 8192, 29568, False)],
@@ -99,7 +100,7 @@ def main():
                     if kind == "gated" and not gated_ok:
                         continue
                     bno = bn // 2 if kind == "gated" else bn
-                    for sp in ((1, 2, 4) if kind == "row" else (1,)):
+                    for sp in (((1, 2, 4, 8) if k >= 8192 else (1, 2, 4)) if kind == "row" else (1,)):
                         wgs = -(-m // bm) * -(-n // bno) * sp
                         if wgs > (640 if n < 65536 else 4096) or wgs < 48 or (k // 64) % sp:
                             continue
