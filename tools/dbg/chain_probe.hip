@@ -1,7 +1,8 @@
 // Can two consecutive GEMV launches of a decode step overlap?  A chain of y = W_i x (N = K = 2048, bf16, batch 1),
 // every launch streaming a different 8-MB matrix, run three ways:
 //   0  one stream, the kernel boundary is the dependency (what the engine does today)
-//   1  one stream, plus the device-side flag protocol (cost of the protocol alone)
+//   1  one stream, plus the device-side flag protocol with agent-scope fences (cost of the protocol alone)
+//   3  one stream, the "light" protocol: no fences, exchanged data through agent-scope relaxed atomics
 //   2  two streams, launch i on stream i & 1 and NO event between them: launch i + 1 prefetches its weight rows
 //      into registers while launch i still runs, then waits on a device counter that launch i's workgroups bump
 //      after their stores ("software dependent launch"); at most two launches are ever in flight
@@ -24,7 +25,10 @@ __device__ __forceinline__ float dot8(const u32x4 &a, const u32x4 &b, float acc)
   return acc;
 }
 
-template <bool FLAGS>
+// PROTO: 0 = none, 1 = fences (agent-scope release / acquire), 2 = "light": no fence — x and y travel through
+// agent-scope relaxed atomic loads / stores (sc1 accesses), the counter bump is ordered behind the y stores by
+// s_waitcnt vmcnt(0) and the barrier
+template <int PROTO>
 __global__ void __launch_bounds__(256) gemv(const uint16_t *__restrict__ w, const uint16_t *x, uint16_t *y,
                                             unsigned *flag_in, unsigned *flag_out, unsigned want, unsigned *err) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -36,6 +40,7 @@ __global__ void __launch_bounds__(256) gemv(const uint16_t *__restrict__ w, cons
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       wr[r][j] = __builtin_nontemporal_load((const u32x4 *)(w + (size_t)(row0 + r) * K + j * 512 + lane * 8));
+  constexpr bool FLAGS = PROTO != 0;
   if (FLAGS) {
     if (threadIdx.x == 0) {
       const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
@@ -48,11 +53,19 @@ __global__ void __launch_bounds__(256) gemv(const uint16_t *__restrict__ w, cons
       }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (PROTO == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   u32x4 xr[4];
+  if (PROTO == 2) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) xr[j] = *(const u32x4 *)(x + j * 512 + lane * 8);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        xr[j][e] = __hip_atomic_load((const uint32_t *)(x + j * 512 + lane * 8) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xr[j] = *(const u32x4 *)(x + j * 512 + lane * 8);
+  }
   float acc[2] = {0.f, 0.f};
 #pragma unroll
   for (int r = 0; r < 2; ++r)
@@ -62,16 +75,16 @@ __global__ void __launch_bounds__(256) gemv(const uint16_t *__restrict__ w, cons
   for (int r = 0; r < 2; ++r)
     for (int off = 32; off; off >>= 1) acc[r] += __shfl_xor(acc[r], off, 64);
   if (lane == 0) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const float v = acc[r] * 0.02f + 1.0f;  // keep the chain's values in range
-      y[row0 + r] = (uint16_t)(__builtin_bit_cast(uint32_t, v) >> 16);
-    }
+    const float v0 = acc[0] * 0.02f + 1.0f, v1 = acc[1] * 0.02f + 1.0f;  // keep the chain's values in range
+    const uint32_t pk = (__builtin_bit_cast(uint32_t, v0) >> 16) | (__builtin_bit_cast(uint32_t, v1) & 0xffff0000u);
+    if (PROTO == 2) __hip_atomic_store((uint32_t *)(y + row0), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *(uint32_t *)(y + row0) = pk;
   }
   if (FLAGS) {
+    if (PROTO == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (PROTO == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __hip_atomic_fetch_add(flag_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -100,13 +113,17 @@ int main(int argc, char **argv) {
     for (int i = 0; i < CHAIN; ++i) {
       hipStream_t st = mode == 2 ? s[i & 1] : s[0];
       if (mode == 0)
-        hipLaunchKernelGGL(gemv<false>, dim3(WGS), dim3(256), 0, st, w[i % NW], xb[i & 1], xb[(i + 1) & 1], nullptr, nullptr, 0u, err);
+        hipLaunchKernelGGL(gemv<0>, dim3(WGS), dim3(256), 0, st, w[i % NW], xb[i & 1], xb[(i + 1) & 1], nullptr, nullptr, 0u, err);
+      else if (mode == 3)
+        hipLaunchKernelGGL(gemv<2>, dim3(WGS), dim3(256), 0, st, w[i % NW], xb[i & 1], xb[(i + 1) & 1], flags + i,
+                           flags + (i + 1) % CHAIN, (i == 0 ? epoch - 1 : epoch) * WGS, err);
       else
-        hipLaunchKernelGGL(gemv<true>, dim3(WGS), dim3(256), 0, st, w[i % NW], xb[i & 1], xb[(i + 1) & 1], flags + i,
+        hipLaunchKernelGGL(gemv<1>, dim3(WGS), dim3(256), 0, st, w[i % NW], xb[i & 1], xb[(i + 1) & 1], flags + i,
                            flags + (i + 1) % CHAIN, (i == 0 ? epoch - 1 : epoch) * WGS, err);
     }
   };
-  for (int mode = 0; mode < MODES; ++mode) {
+  for (int mode : {0, 1, 3}) {
+    if (mode >= MODES && mode != 3) continue;
     for (int graph = 0; graph < 2; ++graph) {
       CK(hipMemset(flags, 0, (CHAIN + 1) * sizeof(unsigned)));
       CK(hipDeviceSynchronize());
