@@ -32,6 +32,14 @@ SHAPES = {
                  ("row", 3584, 18944, False)],
     "lm-heads": [("col", 151936, 1024, False), ("col", 151936, 2048, False), ("col", 152064, 3584, False),
                  ("col", 19008, 8192, False)],
+    # the per-rank shards of Qwen3-1.7B under TP = 2 / 4 / 8 (bench.py --gpus N)
+    "qwen3-1.7b-tp": [("col", 2048, 2048, False), ("row", 2048, 1024, False), ("gated", 3072, 2048, False), ("row", 2048, 3072, False),
+                      ("col", 1024, 2048, False), ("row", 2048, 512, False), ("gated", 1536, 2048, False), ("row", 2048, 1536, False),
+                      ("col", 512, 2048, False), ("row", 2048, 256, False), ("gated", 768, 2048, False), ("row", 2048, 768, False),
+                      ("col", 75968, 2048, False), ("col", 37984, 2048, False), ("col", 18992, 2048, False),
+                      # (under TP the row-parallel outputs go to the all-reduce, not to a K-split norm: plain form)
+                      ("col", 2048, 1024, False), ("col", 2048, 3072, False), ("col", 2048, 512, False),
+                      ("col", 2048, 1536, False), ("col", 2048, 256, False), ("col", 2048, 768, False)],
     "deep-k": [("row", 3584, 18944, False), ("row", 8192, 29568, False), ("row", 8192, 8192, False)],
     "qwen2-72b-tp8": [("col", 1280, 8192, True), ("row", 8192, 1024, False), ("gated", 3696, 8192, False)],
     "qwen2-72b": [("col", 10240, 8192, True), ("row", 8192, 8192, False), ("gated", 29568, 8192, False),
