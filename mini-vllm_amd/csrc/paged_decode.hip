@@ -389,6 +389,9 @@ bool make_plan(int batch, int n_heads, int n_kv_heads, int head_dim, int block_s
   // whole-row loads: HBM likes FEWER concurrent streams (B = 256 x 1024 tokens: 162 us at 512 workgroups,
   // 170 us at 1024, 182 us at 2560; the per-head mapping: 171 us at its best)
   int target = pl->wide ? kTargetWorkgroups / 4 : (pl->mfma ? kTargetWorkgroups / 2 : kTargetWorkgroups);
+  // per-head vector mapping with >= 512 workgroups already (e.g. the 4 q / 2 kv heads of a TP = 4 shard at B = 256): no
+  // split — 45 us against 50 us with the 4-way split and its combine launch
+  if (!pl->mfma && !pl->wide && wg >= 512) target = (int)(wg < (1 << 20) ? wg : (1 << 20));
   if ((flags >> 8) & 0xff) target = ((flags >> 8) & 0xff) * 16;  // tuning aid: bits 8-15 = target workgroups / 16
   int ns = wg > 0 ? (int)((target + wg - 1) / wg) : 1;
   if (ns > max_units) ns = max_units;
