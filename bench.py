@@ -130,16 +130,20 @@ def decode_roofline(engine, args):
     L, nb, bs, hkv, d = ex.kv_cache.shape[1:]
     heads = MODELS[args.model]["num_attention_heads"] // args.gpus
     pairs = []
-    real = hip_ops.paged_decode
+    # the launch is mv_paged_decode, or mv_rope_paged_decode where the layer folds RoPE + the K/V store into it
+    reals = {"paged_decode": hip_ops.paged_decode, "rope_paged_decode": hip_ops.rope_paged_decode}
 
-    def timed(*a, **kw):
-        stream = torch.cuda.current_stream()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        out = real(*a, **kw)
-        e1.record(stream)
-        pairs.append((e0, e1))
-        return out
+    def wrap(real):
+        def timed(*a, **kw):
+            stream = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            out = real(*a, **kw)
+            e1.record(stream)
+            if out is not None:                 # (None: the fused form declined the layout, the plain launch follows)
+                pairs.append((e0, e1))
+            return out
+        return timed
     was_eager = ex.enforce_eager
     ex.enforce_eager = True
     # (Events cannot be recorded inside a captured graph on ROCm — "External events are disallowed in rocm",
@@ -149,12 +153,14 @@ def decode_roofline(engine, args):
     # `event_pair_floor_us` = the same pair around a one-element fill.)
     try:
         engine.step()                       # eager warm-up step (kernels already resident)
-        attn_mod.hip_ops.paged_decode = timed
+        for name, real in reals.items():
+            setattr(attn_mod.hip_ops, name, wrap(real))
         probe_steps = 3
         for _ in range(probe_steps):
             engine.step()
     finally:
-        attn_mod.hip_ops.paged_decode = real
+        for name, real in reals.items():
+            setattr(attn_mod.hip_ops, name, real)
         ex.enforce_eager = was_eager
     torch.cuda.synchronize()
     assert len(pairs) == probe_steps * L

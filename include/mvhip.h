@@ -128,6 +128,24 @@ int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *k_cache,
                     int64_t num_blocks, float scale, void *workspace,
                     size_t ws_bytes, int dtype, int flags, void *stream);
 
+/* K7 + K6 (per head) + K1 + K3 in one launch, for decode steps: q / k / v are the RAW rows of the qkv projection
+ * (views of its output: row strides in elements); the attention kernel applies the per-head RMSNorm (q_norm_w /
+ * k_norm_w, NULL = none) and the rotary embedding to q itself, and the workgroup that reads a sequence's last token
+ * first writes that token's K (normed, rotated) and V rows to cache slot slot_mapping[b] (-1 = no store).  Replaces
+ * mv_rope_qk_store + mv_paged_decode for the flat decode path of QwenAttention.forward
+ * (minivllm/models/qwen_base.py:173-190 with layers/attention.py:436-447) with bit-identical results.  Arguments as in
+ * those two calls.  MV_E_SHAPE for layouts the fused form does not take (fp32, more than 4 query heads per kv head /
+ * the matrix-core kernel): the caller then issues the two launches. */
+int mv_rope_paged_decode(const void *q, int64_t q_stride_tok, const void *k, int64_t k_stride_tok,
+                         const void *v, int64_t v_stride_tok, const int64_t *positions, const float *cos,
+                         const float *sin, int64_t max_pos, const void *q_norm_w, const void *k_norm_w,
+                         float eps, const int32_t *slot_mapping, void *k_cache, void *v_cache,
+                         const int32_t *block_tables, int64_t table_stride, const int32_t *context_lens,
+                         void *out, int batch, int n_heads, int n_kv_heads, int head_dim, int block_size,
+                         int max_blocks, int64_t num_blocks, float scale, void *workspace, size_t ws_bytes,
+                         int dtype, int flags, void *stream);
+
+
 /* K2 — packed varlen causal prefill attention (flash-style, MFMA).
  * Replaces flash_attn_varlen_func / Attention._fallback_attention
  * (minivllm/models/layers/attention.py:422-433, :467-504,554-597).

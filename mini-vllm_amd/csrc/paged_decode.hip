@@ -70,7 +70,40 @@ __device__ __forceinline__ float token_sum(float x) {
   return x;
 }
 
-template <typename Tag, int D, int G, int NLOAD, bool UNIFORM, bool WIDE>
+// one head row (D elements on LPT lanes, VEC per lane): optional RMSNorm over the row (result rounded to dtype) and
+// the NeoX rotation by (cs, sn) — rope_qk_store_kernel's arithmetic and rounding points, statement for statement
+template <typename Tag, int D>
+__device__ __forceinline__ u32x4 norm_rope_row(const u32x4 &raw, const typename elem<Tag>::T *nw, float eps, int sub,
+                                               const float (&cs)[elem<Tag>::VEC], const float (&sn)[elem<Tag>::VEC]) {
+  constexpr int VEC = elem<Tag>::VEC, LPT = D / VEC, HALF = LPT / 2;
+  static_assert(VEC == 8, "16-bit dtypes");
+  float x[VEC];
+  unpack8<Tag>(raw, x);
+  if (nw != nullptr) {
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) ss = fmaf(x[j], x[j], ss);
+    for (int off = 1; off < LPT; off <<= 1) ss += __shfl_xor(ss, off, 64);
+    const float rs = 1.0f / sqrtf(ss / (float)D + eps);
+    float w[VEC];
+    unpack8<Tag>(*reinterpret_cast<const u32x4 *>(nw + sub * VEC), w);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) x[j] = elem<Tag>::ld(elem<Tag>::st(__fmul_rn(__fmul_rn(x[j], rs), w[j])));
+  }
+  float y[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float other;
+    if constexpr (LPT == 16) other = row_ror<8>(x[j]);
+    else other = __shfl_xor(x[j], HALF, 64);
+    const float a = __fmul_rn(x[j], cs[j]);
+    const float b = __fmul_rn(other, sn[j]);
+    y[j] = sub < HALF ? __fsub_rn(a, b) : __fadd_rn(a, b);
+  }
+  return pack8<Tag>(y);
+}
+
+template <typename Tag, int D, int G, int NLOAD, bool UNIFORM, bool WIDE, bool ROPE = false>
 __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
   typedef typename elem<Tag>::T T;
   constexpr int VEC = elem<Tag>::VEC;
@@ -115,6 +148,35 @@ __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
     const int gg = g < g_live ? g : 0;
     const T *qp = (const T *)p.q + (int64_t)b * p.q_stride + (int64_t)(h0 + gg) * D + sub * VEC;
     qraw[g] = *reinterpret_cast<const u32x4 *>(qp);
+  }
+  if constexpr (ROPE) {
+    static_assert(!ROPE || elem<Tag>::VEC == 8, "rope fusion: 16-bit dtypes");
+    // rotary factors of this sequence's position for this lane's dims (rope_qk_store_kernel's table lookup)
+    const int64_t pos = p.positions[b];
+    const bool pos_ok = pos >= 0 && pos < p.max_pos;
+    float cs[VEC], sn[VEC];
+    const int i0 = (sub % (LPT / 2)) * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      cs[j] = pos_ok ? p.cos[pos * (D / 2) + i0 + j] : 1.0f;
+      sn[j] = pos_ok ? p.sin[pos * (D / 2) + i0 + j] : 0.0f;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) qraw[g] = norm_rope_row<Tag, D>(qraw[g], (const T *)p.q_norm_w, p.eps, sub, cs, sn);
+    // the workgroup that will read the sequence's last token writes its K / V rows first (one wave; WIDE: its four
+    // lane groups are the four kv heads, else lane group 0 has the workgroup's kv head)
+    int64_t slot = p.slot_mapping ? (int64_t)p.slot_mapping[b] : -1;
+    if (slot >= p.num_blocks * p.block_size) slot = -1;
+    const int u_last = ctx > 0 ? (ctx - 1) / UNIT : -1;
+    if (slot >= 0 && u_last >= u_begin && u_last < u_end && wave == 0 && (WIDE || grp == 0)) {
+      const u32x4 kraw = *reinterpret_cast<const u32x4 *>((const T *)p.k_new + (int64_t)b * p.k_stride + (int64_t)hkv * D + sub * VEC);
+      const u32x4 vraw = *reinterpret_cast<const u32x4 *>((const T *)p.v_new + (int64_t)b * p.v_stride + (int64_t)hkv * D + sub * VEC);
+      const u32x4 krot = norm_rope_row<Tag, D>(kraw, (const T *)p.k_norm_w, p.eps, sub, cs, sn);
+      *reinterpret_cast<u32x4 *>((T *)p.k_cache + (slot * p.n_kv_heads + hkv) * D + sub * VEC) = krot;
+      *reinterpret_cast<u32x4 *>((T *)p.v_cache + (slot * p.n_kv_heads + hkv) * D + sub * VEC) = vraw;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows are in L2 before any wave of the workgroup asks
+    }
+    __syncthreads();
   }
 
   float m[G], l[G], acc[G][VEC];
@@ -403,24 +465,32 @@ bool make_plan(int batch, int n_heads, int n_kv_heads, int head_dim, int block_s
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-template <typename Tag, int D, int G, int NLOAD>
-void launch_g(const DecodeParams &p, const DecodePlan &pl, int batch, hipStream_t stream) {
+template <typename Tag, int D, int G, int NLOAD, bool ROPE>
+void launch_gr(const DecodeParams &p, const DecodePlan &pl, int batch, hipStream_t stream) {
   dim3 block(256);
   if constexpr (G <= 4) {
     if (pl.wide) {
       dim3 grid(p.n_kv_heads / (64 / (D / elem<Tag>::VEC)), pl.nsplit, batch);
       if (pl.uniform)
-        hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, true, true>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, true, true, ROPE>), grid, block, 0, stream, p);
       else
-        hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, false, true>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, false, true, ROPE>), grid, block, 0, stream, p);
       return;
     }
   }
   dim3 grid(p.n_kv_heads * pl.n_chunks, pl.nsplit, batch);
   if (pl.uniform)
-    hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, true, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, true, false, ROPE>), grid, block, 0, stream, p);
   else
-    hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, false, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((paged_decode_kernel<Tag, D, G, NLOAD, false, false, ROPE>), grid, block, 0, stream, p);
+}
+
+template <typename Tag, int D, int G, int NLOAD>
+void launch_g(const DecodeParams &p, const DecodePlan &pl, int batch, hipStream_t stream) {
+  if constexpr (elem<Tag>::VEC == 8 && G <= 4) {   // (rope fusion: 16-bit dtypes, up to 4 query heads per kv head)
+    if (p.positions != nullptr) return launch_gr<Tag, D, G, NLOAD, true>(p, pl, batch, stream);
+  }
+  launch_gr<Tag, D, G, NLOAD, false>(p, pl, batch, stream);
 }
 
 template <typename Tag, int D>
@@ -471,12 +541,72 @@ extern "C" size_t mv_paged_decode_workspace_bytes(int batch, int n_heads, int n_
   return align256(slots * head_dim * sizeof(float)) + align256(slots * 2 * sizeof(float));
 }
 
+namespace {
+struct RopeArgs {
+  const void *k_new, *v_new;
+  int64_t k_stride, v_stride;
+  const int64_t *positions;
+  const float *cos, *sin;
+  int64_t max_pos;
+  const void *q_norm_w, *k_norm_w;
+  float eps;
+  const int32_t *slot_mapping;
+};
+int paged_decode_impl(const void *q, int64_t q_stride_tok, const void *k_cache,
+                      const void *v_cache, const int32_t *block_tables,
+                      int64_t table_stride, const int32_t *context_lens, void *out,
+                      int batch, int n_heads, int n_kv_heads, int head_dim,
+                      int block_size, int max_blocks, int64_t num_blocks, float scale,
+                      void *workspace, size_t ws_bytes, int dtype, int flags, void *stream, const RopeArgs *rope);
+}  // namespace
+
 extern "C" int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *k_cache,
                                const void *v_cache, const int32_t *block_tables,
                                int64_t table_stride, const int32_t *context_lens, void *out,
                                int batch, int n_heads, int n_kv_heads, int head_dim,
                                int block_size, int max_blocks, int64_t num_blocks, float scale,
                                void *workspace, size_t ws_bytes, int dtype, int flags, void *stream) {
+  return paged_decode_impl(q, q_stride_tok, k_cache, v_cache, block_tables, table_stride, context_lens, out, batch,
+                           n_heads, n_kv_heads, head_dim, block_size, max_blocks, num_blocks, scale, workspace, ws_bytes,
+                           dtype, flags, stream, nullptr);
+}
+
+// K7 + K6 (per head) + K1 + K3 in ONE launch for decode steps: q / k / v are the RAW rows of the qkv projection; the
+// attention kernel norms and rotates q itself, and the workgroup that reads a sequence's last token first writes that
+// token's K (normed, rotated) and V into the cache (see paged_decode_kernel<ROPE>).  Bit-identical to
+// mv_rope_qk_store followed by mv_paged_decode.  MV_E_SHAPE for layouts the fused form does not take (fp32, more than
+// 4 query heads per kv head, the matrix-core kernel): the caller then issues the two launches.
+extern "C" int mv_rope_paged_decode(const void *q, int64_t q_stride_tok, const void *k, int64_t k_stride_tok,
+                                    const void *v, int64_t v_stride_tok, const int64_t *positions, const float *cos,
+                                    const float *sin, int64_t max_pos, const void *q_norm_w, const void *k_norm_w,
+                                    float eps, const int32_t *slot_mapping, void *k_cache, void *v_cache,
+                                    const int32_t *block_tables, int64_t table_stride, const int32_t *context_lens,
+                                    void *out, int batch, int n_heads, int n_kv_heads, int head_dim, int block_size,
+                                    int max_blocks, int64_t num_blocks, float scale, void *workspace, size_t ws_bytes,
+                                    int dtype, int flags, void *stream) {
+  if (batch == 0) return MV_OK;
+  if (!k || !v || !positions || !cos || !sin || !slot_mapping) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (max_blocks == 0 || num_blocks == 0 || n_kv_heads <= 0 || n_heads % n_kv_heads) return MV_E_SHAPE;
+  if (!mv_aligned16(k) || !mv_aligned16(v) || (k_stride_tok & 7) || (v_stride_tok & 7) ||
+      (q_norm_w && !mv_aligned16(q_norm_w)) || (k_norm_w && !mv_aligned16(k_norm_w)))
+    return MV_E_ALIGN;
+  DecodePlan pl;
+  if (!make_plan(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks, dtype, flags, &pl)) return MV_E_SHAPE;
+  if (pl.mfma || pl.n_chunks != 1 || pl.g_chunk > 4) return MV_E_SHAPE;
+  const RopeArgs rope{k, v, k_stride_tok, v_stride_tok, positions, cos, sin, max_pos, q_norm_w, k_norm_w, eps, slot_mapping};
+  return paged_decode_impl(q, q_stride_tok, k_cache, v_cache, block_tables, table_stride, context_lens, out, batch,
+                           n_heads, n_kv_heads, head_dim, block_size, max_blocks, num_blocks, scale, workspace, ws_bytes,
+                           dtype, flags, stream, &rope);
+}
+
+namespace {
+int paged_decode_impl(const void *q, int64_t q_stride_tok, const void *k_cache,
+                      const void *v_cache, const int32_t *block_tables,
+                      int64_t table_stride, const int32_t *context_lens, void *out,
+                      int batch, int n_heads, int n_kv_heads, int head_dim,
+                      int block_size, int max_blocks, int64_t num_blocks, float scale,
+                      void *workspace, size_t ws_bytes, int dtype, int flags, void *stream, const RopeArgs *rope) {
   if (batch == 0) return MV_OK;
   if (!q || !out || !context_lens) return MV_E_NULLPTR;
   if (batch < 0 || n_heads <= 0 || block_size <= 0 || max_blocks < 0 || num_blocks < 0)
@@ -525,6 +655,11 @@ extern "C" int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *
     p.ws_acc = (float *)workspace;
     p.ws_ml = (float *)((char *)workspace + acc_bytes);
   }
+  if (rope) {
+    p.k_new = rope->k_new, p.v_new = rope->v_new, p.k_stride = rope->k_stride, p.v_stride = rope->v_stride;
+    p.positions = rope->positions, p.cos = rope->cos, p.sin = rope->sin, p.max_pos = rope->max_pos;
+    p.q_norm_w = rope->q_norm_w, p.k_norm_w = rope->k_norm_w, p.eps = rope->eps, p.slot_mapping = rope->slot_mapping;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (head_dim == 128) {
     MV_DISPATCH_DTYPE(dtype, return (launch_d<Tag, 128>(p, pl, batch, dtype, flags, st)));
@@ -533,3 +668,4 @@ extern "C" int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *
   }
   return MV_OK;
 }
+}  // namespace

@@ -39,6 +39,10 @@ _SIGNATURES = {
     "mv_paged_decode": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                 c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_float,
                                 c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "mv_rope_paged_decode": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                     c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_int64, c_float, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "mv_prefill_varlen": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                   c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
@@ -103,6 +107,7 @@ class MvHipError(RuntimeError):
 # The C-ABI reads no environment: the overrides below are read HERE, once, and passed as explicit arguments.
 MV_DECODE_VECTOR, MV_DECODE_MFMA, MV_DECODE_KLDS_OFF, MV_DECODE_KLDS_ON, MV_DECODE_PER_HEAD = 1, 2, 4, 8, 16
 MV_PREFILL_SIMPLE = 1
+MV_E_SHAPE = -2   # include/mvhip.h
 
 
 def _decode_flags_from_env() -> int:
@@ -348,6 +353,42 @@ def paged_decode(q, k_cache, v_cache, block_tables, context_lens, scale: float, 
 
 
 # ---------------------------------------------------------------- K2
+def rope_paged_decode(q, k, v, positions, cos, sin, q_norm_w, k_norm_w, eps: float, slot_mapping,
+                      k_cache, v_cache, block_tables, context_lens, scale: float, flags: int | None = None):
+    """Decode step of one layer in ONE launch: q [B,H,D], k/v [B,Hkv,D] RAW rows of the qkv projection (views are
+    fine) -> per-head RMSNorm (weights or None) + RoPE on q and k, the new K/V rows stored at ``slot_mapping``, paged
+    attention over ``block_tables`` / ``context_lens`` (which count the new token).  Returns [B,H,D], or None when
+    the fused kernel does not take the layout (the caller then runs rope_qk_store + paged_decode)."""
+    _need_cuda(q, k, v, k_cache, v_cache, block_tables, context_lens, slot_mapping)
+    b, h, d = q.shape
+    hkv = k.shape[1]
+    nb, bs = k_cache.shape[0], k_cache.shape[1]
+    if q.dtype not in (torch.bfloat16, torch.float16) or k_cache.dtype != q.dtype or slot_mapping.numel() != b:
+        return None
+    for x in (q, k, v):
+        if x.stride(-1) != 1 or x.stride(1) != d:
+            return None
+    bt, cl = _i32(block_tables), _i32(context_lens)
+    if bt.dim() != 2 or bt.stride(1) != 1 or bt.shape[1] == 0:
+        return None
+    flags = DECODE_FLAGS if flags is None else flags
+    ws_bytes = paged_decode_workspace_bytes(b, h, hkv, d, bs, bt.shape[1], flags)
+    ws = workspace(ws_bytes, q.device)
+    out = torch.empty((b, h, d), dtype=q.dtype, device=q.device)
+    pos = positions if positions.dtype == torch.int64 else positions.to(torch.int64)
+    qn = q_norm_w if q_norm_w is None or q_norm_w.dtype == q.dtype else q_norm_w.to(q.dtype)
+    kn = k_norm_w if k_norm_w is None or k_norm_w.dtype == q.dtype else k_norm_w.to(q.dtype)
+    rc = _lib.mv_rope_paged_decode(
+        q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), pos.data_ptr(),
+        cos.data_ptr(), sin.data_ptr(), cos.shape[0], _ptr(qn), _ptr(kn), float(eps), _i32(slot_mapping).data_ptr(),
+        k_cache.data_ptr(), v_cache.data_ptr(), bt.data_ptr(), bt.stride(0), cl.data_ptr(), out.data_ptr(), b, h, hkv,
+        d, bs, bt.shape[1], nb, float(scale), ws.data_ptr(), ws.numel(), _dt(q), flags, _stream())
+    if rc == MV_E_SHAPE:
+        return None
+    _check(rc, "mv_rope_paged_decode")
+    return out
+
+
 def prefill_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, scale: float,
                    k_cache=None, v_cache=None, block_tables=None, out=None, flags: int | None = None):
     """Packed causal prefill.  Contiguous K/V (k,v [Tk,Hkv,D]) unless ``block_tables`` is
@@ -481,7 +522,6 @@ def gate_up_silu_small_m(x, weight, shape: int = 0, packed=None):
 
 
 NORM_FUSED_MAX_ROWS = 4
-MV_E_SHAPE = -2   # include/mvhip.h
 
 
 def norm_linear_small_m_ok(x, n_rows_w: int, packed) -> bool:

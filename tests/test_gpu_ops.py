@@ -139,6 +139,51 @@ def test_paged_decode_whole_row_and_per_head_mappings_agree(H):
     torch.testing.assert_close(wide.float(), per_head.float(), rtol=2 ** -7, atol=2e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("layout", [(16, 8, 128, True), (16, 8, 128, False), (6, 2, 128, True), (4, 4, 64, False),
+                                    (12, 4, 128, True), (2, 1, 128, True)])
+def test_rope_and_store_folded_into_paged_decode_are_bit_identical(H, dtype, layout):
+    """mv_rope_paged_decode == mv_rope_qk_store followed by mv_paged_decode, bit for bit: the attention output AND the
+    K/V cache afterwards (only the new token's rows may change), with and without the per-head norms, on raw q/k/v
+    that are views of one qkv tensor, ragged contexts (split and unsplit), a graph-padding row (slot -1, context 0)."""
+    Hq, Hkv, D, norms = layout
+    bs = 64
+    ctxs = [1, 64, 65, 300, 1000, 2049, 0]
+    B = len(ctxs)
+    kc, vc, table = _make_paged(B - 1, Hkv, D, bs, ctxs[:-1], dtype, seed=51)
+    table = torch.cat([table, torch.full((1, table.shape[1]), -1, dtype=torch.int32)])
+    qkv = _randn(B, (Hq + 2 * Hkv) * D, dtype=dtype, seed=52).to(DEV)
+    q = qkv[:, :Hq * D].view(B, Hq, D)
+    k = qkv[:, Hq * D:(Hq + Hkv) * D].view(B, Hkv, D)
+    v = qkv[:, (Hq + Hkv) * D:].view(B, Hkv, D)
+    ctx = torch.tensor(ctxs, dtype=torch.int32)
+    pos = (ctx.long() - 1).clamp(min=0)
+    slots = torch.tensor([int(table[b, (c - 1) // bs]) * bs + (c - 1) % bs if c > 0 else -1 for b, c in enumerate(ctxs)],
+                         dtype=torch.int32)
+    half = D // 2
+    ang = torch.arange(4096, dtype=torch.float32)[:, None] * (10000.0 ** (-torch.arange(half, dtype=torch.float32) / half))[None]
+    cos, sin = ang.cos().to(DEV), ang.sin().to(DEV)
+    qn = (1.0 + 0.1 * _randn(D, dtype=torch.float32, seed=53)).to(dtype).to(DEV) if norms else None
+    kn = (1.0 + 0.1 * _randn(D, dtype=torch.float32, seed=54)).to(dtype).to(DEV) if norms else None
+    scale = D ** -0.5
+    kc1, vc1, kc2, vc2 = kc.to(DEV), vc.to(DEV), kc.to(DEV), vc.to(DEV)
+    q_rot, _ = H.rope_qk_store(q, k, v, pos.to(DEV), cos, sin, qn, kn, 1e-6, kc1, vc1, slots.to(DEV), want_k_out=False)
+    want = H.paged_decode(q_rot, kc1, vc1, table.to(DEV), ctx.to(DEV), scale)
+    got = H.rope_paged_decode(q, k, v, pos.to(DEV), cos, sin, qn, kn, 1e-6, slots.to(DEV), kc2, vc2, table.to(DEV),
+                              ctx.to(DEV), scale)
+    assert got is not None
+    assert torch.equal(got, want)
+    assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
+    assert not torch.equal(kc2.cpu(), kc)                       # the new rows were written
+    # layouts the fused form declines (matrix-core kernel) come back as None, nothing written
+    big = _randn(2, (28 + 8) * 128, dtype=dtype, seed=55).to(DEV)
+    none = H.rope_paged_decode(big[:, :28 * 128].view(2, 28, 128), big[:, 28 * 128:32 * 128].view(2, 4, 128),
+                               big[:, 32 * 128:].view(2, 4, 128), pos[:2].to(DEV), cos[:, :64], sin[:, :64], None, None,
+                               1e-6, slots[:2].to(DEV), *[_randn(8, 64, 4, 128, dtype=dtype, seed=1).to(DEV)] * 2,
+                               table[:2].to(DEV), ctx[:2].to(DEV), scale)
+    assert none is None
+
+
 def test_paged_decode_edge_cases(H):
     dtype = torch.bfloat16
     B, Hq, Hkv, D, bs = 4, 16, 8, 128, 64
