@@ -70,39 +70,6 @@ __device__ __forceinline__ float token_sum(float x) {
   return x;
 }
 
-// one head row (D elements on LPT lanes, VEC per lane): optional RMSNorm over the row (result rounded to dtype) and
-// the NeoX rotation by (cs, sn) — rope_qk_store_kernel's arithmetic and rounding points, statement for statement
-template <typename Tag, int D>
-__device__ __forceinline__ u32x4 norm_rope_row(const u32x4 &raw, const typename elem<Tag>::T *nw, float eps, int sub,
-                                               const float (&cs)[elem<Tag>::VEC], const float (&sn)[elem<Tag>::VEC]) {
-  constexpr int VEC = elem<Tag>::VEC, LPT = D / VEC, HALF = LPT / 2;
-  static_assert(VEC == 8, "16-bit dtypes");
-  float x[VEC];
-  unpack8<Tag>(raw, x);
-  if (nw != nullptr) {
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) ss = fmaf(x[j], x[j], ss);
-    for (int off = 1; off < LPT; off <<= 1) ss += __shfl_xor(ss, off, 64);
-    const float rs = 1.0f / sqrtf(ss / (float)D + eps);
-    float w[VEC];
-    unpack8<Tag>(*reinterpret_cast<const u32x4 *>(nw + sub * VEC), w);
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) x[j] = elem<Tag>::ld(elem<Tag>::st(__fmul_rn(__fmul_rn(x[j], rs), w[j])));
-  }
-  float y[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) {
-    float other;
-    if constexpr (LPT == 16) other = row_ror<8>(x[j]);
-    else other = __shfl_xor(x[j], HALF, 64);
-    const float a = __fmul_rn(x[j], cs[j]);
-    const float b = __fmul_rn(other, sn[j]);
-    y[j] = sub < HALF ? __fsub_rn(a, b) : __fadd_rn(a, b);
-  }
-  return pack8<Tag>(y);
-}
-
 template <typename Tag, int D, int G, int NLOAD, bool UNIFORM, bool WIDE, bool ROPE = false>
 __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
   typedef typename elem<Tag>::T T;
@@ -574,8 +541,9 @@ extern "C" int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *
 // K7 + K6 (per head) + K1 + K3 in ONE launch for decode steps: q / k / v are the RAW rows of the qkv projection; the
 // attention kernel norms and rotates q itself, and the workgroup that reads a sequence's last token first writes that
 // token's K (normed, rotated) and V into the cache (see paged_decode_kernel<ROPE>).  Bit-identical to
-// mv_rope_qk_store followed by mv_paged_decode.  MV_E_SHAPE for layouts the fused form does not take (fp32, more than
-// 4 query heads per kv head, the matrix-core kernel): the caller then issues the two launches.
+// mv_rope_qk_store followed by mv_paged_decode.  MV_E_SHAPE for layouts the fused form does not take (fp32; more than
+// 16 query heads per kv head; the matrix-core kernel (>= 4 query heads per kv head) WITH head norms): the caller then
+// issues the two launches.
 extern "C" int mv_rope_paged_decode(const void *q, int64_t q_stride_tok, const void *k, int64_t k_stride_tok,
                                     const void *v, int64_t v_stride_tok, const int64_t *positions, const float *cos,
                                     const float *sin, int64_t max_pos, const void *q_norm_w, const void *k_norm_w,
@@ -593,7 +561,9 @@ extern "C" int mv_rope_paged_decode(const void *q, int64_t q_stride_tok, const v
     return MV_E_ALIGN;
   DecodePlan pl;
   if (!make_plan(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks, dtype, flags, &pl)) return MV_E_SHAPE;
-  if (pl.mfma || pl.n_chunks != 1 || pl.g_chunk > 4) return MV_E_SHAPE;
+  // vector kernel: up to 4 query heads per kv head; matrix-core kernel: one chunk of <= 16 heads and no head norms
+  if (pl.n_chunks != 1) return MV_E_SHAPE;
+  if (pl.mfma ? (q_norm_w != nullptr || k_norm_w != nullptr || head_dim != 128) : pl.g_chunk > 4) return MV_E_SHAPE;
   const RopeArgs rope{k, v, k_stride_tok, v_stride_tok, positions, cos, sin, max_pos, q_norm_w, k_norm_w, eps, slot_mapping};
   return paged_decode_impl(q, q_stride_tok, k_cache, v_cache, block_tables, table_stride, context_lens, out, batch,
                            n_heads, n_kv_heads, head_dim, block_size, max_blocks, num_blocks, scale, workspace, ws_bytes,

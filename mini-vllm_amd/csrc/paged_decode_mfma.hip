@@ -64,7 +64,11 @@ __device__ __forceinline__ int v_off(int lrow, int ch) {
 
 // KLDS: K also goes through LDS (DMA in whole 256-B rows, XOR-swizzled on the source side, A operand by
 // ds_read_b128) instead of 16 rows x 64 B per load instruction straight into the A-operand registers.
-template <typename Tag, bool KLDS>
+// ROPE (mv_rope_paged_decode, no head norms): q arrives as the raw rows of the qkv projection and is rotated in place —
+// in the Q^T fragment layout a lane holds dims 32s + 8 quad + j, so the rotation partner d + 64 is fragment s + 2 of the
+// SAME lane — and the workgroup (chunk 0) whose tiles hold the sequence's last token first writes that token's rotated K
+// and raw V rows into the cache (wave 0, in rope_qk_store_kernel's 16-lanes-per-row layout).
+template <typename Tag, bool KLDS, bool ROPE = false>
 __global__ void __launch_bounds__(256, KLDS ? 2 : 4) paged_decode_mfma_kernel(DecodeParams p, int n_chunks) {
   typedef typename elem<Tag>::T T;
   __shared__ __attribute__((aligned(16))) char smem[KLDS ? SMEM_BYTES_KLDS : SMEM_BYTES];
@@ -96,6 +100,49 @@ __global__ void __launch_bounds__(256, KLDS ? 2 : 4) paged_decode_mfma_kernel(De
       const u32x4 zero = {0u, 0u, 0u, 0u};
       qf[s] = q_ok ? *reinterpret_cast<const u32x4 *>(qp + 32 * s) : zero;
     }
+  }
+  if constexpr (ROPE) {
+    const int64_t pos = p.positions[b];
+    const bool pos_ok = pos >= 0 && pos < p.max_pos;
+    // q: dims d = 32 s + 8 quad + j (s = 0, 1) pair with d + 64 (fragment s + 2); products rounded separately, like
+    // rope_qk_store_kernel: y[d] = x[d] cos - x[d+64] sin, y[d+64] = x[d+64] cos + x[d] sin
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float lo[8], hi[8], ylo[8], yhi[8];
+      unpack8<Tag>(qf[s], lo);
+      unpack8<Tag>(qf[s + 2], hi);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = 32 * s + 8 * quad + j;
+        const float c = pos_ok ? p.cos[pos * (D / 2) + i] : 1.0f, sn = pos_ok ? p.sin[pos * (D / 2) + i] : 0.0f;
+        ylo[j] = __fsub_rn(__fmul_rn(lo[j], c), __fmul_rn(hi[j], sn));
+        yhi[j] = __fadd_rn(__fmul_rn(hi[j], c), __fmul_rn(lo[j], sn));
+      }
+      const bool live = i16 < g_live;   // (rows beyond the live heads stay zero)
+      qf[s] = live ? pack8<Tag>(ylo) : u32x4{0u, 0u, 0u, 0u};
+      qf[s + 2] = live ? pack8<Tag>(yhi) : u32x4{0u, 0u, 0u, 0u};
+    }
+    // the new token's K / V rows: written by the workgroup (chunk 0) that will read them, before anybody does
+    int64_t slot = p.slot_mapping ? (int64_t)p.slot_mapping[b] : -1;
+    if (slot >= p.num_blocks * p.block_size) slot = -1;
+    const int u_last = ctx > 0 ? (ctx - 1) / UNIT : -1;
+    if (slot >= 0 && chunk == 0 && u_last >= u_begin && u_last < u_end && wave == 0 && lane < 16) {
+      const int sub = lane;
+      float cs[8], sn[8];
+      const int i0 = (sub % 8) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        cs[j] = pos_ok ? p.cos[pos * (D / 2) + i0 + j] : 1.0f;
+        sn[j] = pos_ok ? p.sin[pos * (D / 2) + i0 + j] : 0.0f;
+      }
+      const u32x4 kraw = *reinterpret_cast<const u32x4 *>((const T *)p.k_new + (int64_t)b * p.k_stride + (int64_t)hkv * D + sub * 8);
+      const u32x4 vraw = *reinterpret_cast<const u32x4 *>((const T *)p.v_new + (int64_t)b * p.v_stride + (int64_t)hkv * D + sub * 8);
+      const u32x4 krot = norm_rope_row<Tag, D>(kraw, nullptr, 0.f, sub, cs, sn);
+      *reinterpret_cast<u32x4 *>((T *)p.k_cache + (slot * p.n_kv_heads + hkv) * D + sub * 8) = krot;
+      *reinterpret_cast<u32x4 *>((T *)p.v_cache + (slot * p.n_kv_heads + hkv) * D + sub * 8) = vraw;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
   }
   f32x4 oacc[8];
 #pragma unroll
@@ -282,15 +329,18 @@ int mv_paged_decode_mfma_launch(const DecodeParams &p, int n_chunks, int nsplit,
   // 16 rows x 64 B per load: 5.5 -> 5.9 TB/s on Qwen2-7B heads at B=256, 5.8 -> 6.4 at ctx 4096); with fewer
   // workgroups its 2-per-CU residency (64 KiB of LDS) costs more than it gains.  The caller's flags can force.
   const bool klds = force >= 0 ? force == 1 : (int64_t)grid.x * grid.z >= 1024;
-  if (dtype == MV_BF16) {
-    if (klds) hipLaunchKernelGGL((paged_decode_mfma_kernel<bf16_tag, true>), grid, block, 0, stream, p, n_chunks);
-    else hipLaunchKernelGGL((paged_decode_mfma_kernel<bf16_tag, false>), grid, block, 0, stream, p, n_chunks);
-  } else if (dtype == MV_F16) {
-    if (klds) hipLaunchKernelGGL((paged_decode_mfma_kernel<f16_tag, true>), grid, block, 0, stream, p, n_chunks);
-    else hipLaunchKernelGGL((paged_decode_mfma_kernel<f16_tag, false>), grid, block, 0, stream, p, n_chunks);
-  } else {
-    return MV_E_DTYPE;
-  }
+  const bool rope = p.positions != nullptr;   // mv_rope_paged_decode (the caller has checked: no head norms, one chunk)
+#define MV_MFMA_LAUNCH(TAG)                                                                                        \
+  do {                                                                                                             \
+    if (rope && klds) hipLaunchKernelGGL((paged_decode_mfma_kernel<TAG, true, true>), grid, block, 0, stream, p, n_chunks);   \
+    else if (rope) hipLaunchKernelGGL((paged_decode_mfma_kernel<TAG, false, true>), grid, block, 0, stream, p, n_chunks);     \
+    else if (klds) hipLaunchKernelGGL((paged_decode_mfma_kernel<TAG, true>), grid, block, 0, stream, p, n_chunks);            \
+    else hipLaunchKernelGGL((paged_decode_mfma_kernel<TAG, false>), grid, block, 0, stream, p, n_chunks);                     \
+  } while (0)
+  if (dtype == MV_BF16) MV_MFMA_LAUNCH(bf16_tag);
+  else if (dtype == MV_F16) MV_MFMA_LAUNCH(f16_tag);
+  else return MV_E_DTYPE;
+#undef MV_MFMA_LAUNCH
   MV_LAUNCH_CHECK();
   return MV_OK;
 }
