@@ -134,8 +134,8 @@ int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *k_cache,
  * first writes that token's K (normed, rotated) and V rows to cache slot slot_mapping[b] (-1 = no store).  Replaces
  * mv_rope_qk_store + mv_paged_decode for the flat decode path of QwenAttention.forward
  * (minivllm/models/qwen_base.py:173-190 with layers/attention.py:436-447) with bit-identical results.  Arguments as in
- * those two calls.  MV_E_SHAPE for layouts the fused form does not take (fp32; more than 16 query heads per kv head;
- * 4..16 query heads per kv head together with head norms): the caller then issues the two launches. */
+ * those two calls.  MV_E_SHAPE for layouts the fused form does not take (fp32; more than 16 query heads per kv
+ * head): the caller then issues the two launches. */
 int mv_rope_paged_decode(const void *q, int64_t q_stride_tok, const void *k, int64_t k_stride_tok,
                          const void *v, int64_t v_stride_tok, const int64_t *positions, const float *cos,
                          const float *sin, int64_t max_pos, const void *q_norm_w, const void *k_norm_w,

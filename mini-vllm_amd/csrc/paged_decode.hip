@@ -542,8 +542,7 @@ extern "C" int mv_paged_decode(const void *q, int64_t q_stride_tok, const void *
 // attention kernel norms and rotates q itself, and the workgroup that reads a sequence's last token first writes that
 // token's K (normed, rotated) and V into the cache (see paged_decode_kernel<ROPE>).  Bit-identical to
 // mv_rope_qk_store followed by mv_paged_decode.  MV_E_SHAPE for layouts the fused form does not take (fp32; more than
-// 16 query heads per kv head; the matrix-core kernel (>= 4 query heads per kv head) WITH head norms): the caller then
-// issues the two launches.
+// 16 query heads per kv head): the caller then issues the two launches.
 extern "C" int mv_rope_paged_decode(const void *q, int64_t q_stride_tok, const void *k, int64_t k_stride_tok,
                                     const void *v, int64_t v_stride_tok, const int64_t *positions, const float *cos,
                                     const float *sin, int64_t max_pos, const void *q_norm_w, const void *k_norm_w,
@@ -561,9 +560,9 @@ extern "C" int mv_rope_paged_decode(const void *q, int64_t q_stride_tok, const v
     return MV_E_ALIGN;
   DecodePlan pl;
   if (!make_plan(batch, n_heads, n_kv_heads, head_dim, block_size, max_blocks, dtype, flags, &pl)) return MV_E_SHAPE;
-  // vector kernel: up to 4 query heads per kv head; matrix-core kernel: one chunk of <= 16 heads and no head norms
+  // vector kernel: up to 4 query heads per kv head; matrix-core kernel: one chunk of <= 16 heads
   if (pl.n_chunks != 1) return MV_E_SHAPE;
-  if (pl.mfma ? (q_norm_w != nullptr || k_norm_w != nullptr || head_dim != 128) : pl.g_chunk > 4) return MV_E_SHAPE;
+  if (pl.mfma ? head_dim != 128 : pl.g_chunk > 4) return MV_E_SHAPE;
   const RopeArgs rope{k, v, k_stride_tok, v_stride_tok, positions, cos, sin, max_pos, q_norm_w, k_norm_w, eps, slot_mapping};
   return paged_decode_impl(q, q_stride_tok, k_cache, v_cache, block_tables, table_stride, context_lens, out, batch,
                            n_heads, n_kv_heads, head_dim, block_size, max_blocks, num_blocks, scale, workspace, ws_bytes,

@@ -64,7 +64,7 @@ __device__ __forceinline__ int v_off(int lrow, int ch) {
 
 // KLDS: K also goes through LDS (DMA in whole 256-B rows, XOR-swizzled on the source side, A operand by
 // ds_read_b128) instead of 16 rows x 64 B per load instruction straight into the A-operand registers.
-// ROPE (mv_rope_paged_decode, no head norms): q arrives as the raw rows of the qkv projection and is rotated in place —
+// ROPE (mv_rope_paged_decode): q arrives as the raw rows of the qkv projection and is rotated in place —
 // in the Q^T fragment layout a lane holds dims 32s + 8 quad + j, so the rotation partner d + 64 is fragment s + 2 of the
 // SAME lane — and the workgroup (chunk 0) whose tiles hold the sequence's last token first writes that token's rotated K
 // and raw V rows into the cache (wave 0, in rope_qk_store_kernel's 16-lanes-per-row layout).
@@ -104,6 +104,32 @@ __global__ void __launch_bounds__(256, KLDS ? 2 : 4) paged_decode_mfma_kernel(De
   if constexpr (ROPE) {
     const int64_t pos = p.positions[b];
     const bool pos_ok = pos >= 0 && pos < p.max_pos;
+    if (p.q_norm_w != nullptr) {
+      // per-head RMSNorm of q, rope_qk_store_kernel's sum order: there a head row sits on 16 lanes "sub" (8 dims each,
+      // fmaf chain over them) and the lane sums meet in a butterfly over sub ^ 1, 2, 4, 8.  Here sub = 4 s + quad:
+      // sub ^ 1 / ^ 2 are the lanes quad ^ 1 / ^ 2 (16 / 32 lanes away), sub ^ 4 / ^ 8 are fragments s ^ 1 / s ^ 2
+      float x[4][8], ss[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        unpack8<Tag>(qf[s], x[s]);
+        ss[s] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss[s] = fmaf(x[s][j], x[s][j], ss[s]);
+        ss[s] += __shfl_xor(ss[s], 16, 64);
+        ss[s] += __shfl_xor(ss[s], 32, 64);
+      }
+      const float a0 = ss[0] + ss[1], a1 = ss[1] + ss[0], a2 = ss[2] + ss[3], a3 = ss[3] + ss[2];  // sub ^ 4
+      const float tot[4] = {a0 + a2, a1 + a3, a2 + a0, a3 + a1};                                       // sub ^ 8
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float rs = 1.0f / sqrtf(tot[s] / (float)D + p.eps);
+        float w[8];
+        unpack8<Tag>(*reinterpret_cast<const u32x4 *>((const T *)p.q_norm_w + 32 * s + 8 * quad), w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[s][j] = elem<Tag>::ld(elem<Tag>::st(__fmul_rn(__fmul_rn(x[s][j], rs), w[j])));
+        qf[s] = pack8<Tag>(x[s]);
+      }
+    }
     // q: dims d = 32 s + 8 quad + j (s = 0, 1) pair with d + 64 (fragment s + 2); products rounded separately, like
     // rope_qk_store_kernel: y[d] = x[d] cos - x[d+64] sin, y[d+64] = x[d+64] cos + x[d] sin
 #pragma unroll
@@ -137,7 +163,7 @@ __global__ void __launch_bounds__(256, KLDS ? 2 : 4) paged_decode_mfma_kernel(De
       }
       const u32x4 kraw = *reinterpret_cast<const u32x4 *>((const T *)p.k_new + (int64_t)b * p.k_stride + (int64_t)hkv * D + sub * 8);
       const u32x4 vraw = *reinterpret_cast<const u32x4 *>((const T *)p.v_new + (int64_t)b * p.v_stride + (int64_t)hkv * D + sub * 8);
-      const u32x4 krot = norm_rope_row<Tag, D>(kraw, nullptr, 0.f, sub, cs, sn);
+      const u32x4 krot = norm_rope_row<Tag, D>(kraw, (const T *)p.k_norm_w, p.eps, sub, cs, sn);
       *reinterpret_cast<u32x4 *>((T *)p.k_cache + (slot * p.n_kv_heads + hkv) * D + sub * 8) = krot;
       *reinterpret_cast<u32x4 *>((T *)p.v_cache + (slot * p.n_kv_heads + hkv) * D + sub * 8) = vraw;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -142,7 +142,8 @@ def test_paged_decode_whole_row_and_per_head_mappings_agree(H):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("layout", [(16, 8, 128, True), (16, 8, 128, False), (6, 2, 128, True), (4, 4, 64, False),
                                     (12, 4, 128, True), (2, 1, 128, True),
-                                    (28, 4, 128, False), (8, 1, 128, False), (32, 8, 128, False)])   # matrix-core kernel
+                                    (28, 4, 128, False), (8, 1, 128, False), (32, 8, 128, False),     # matrix-core kernel
+                                    (32, 8, 128, True), (8, 1, 128, True), (20, 4, 128, True)])       # ... with head norms
 def test_rope_and_store_folded_into_paged_decode_are_bit_identical(H, dtype, layout):
     """mv_rope_paged_decode == mv_rope_qk_store followed by mv_paged_decode, bit for bit: the attention output AND the
     K/V cache afterwards (only the new token's rows may change), with and without the per-head norms, on raw q/k/v
@@ -176,11 +177,10 @@ def test_rope_and_store_folded_into_paged_decode_are_bit_identical(H, dtype, lay
     assert torch.equal(got, want)
     assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
     assert not torch.equal(kc2.cpu(), kc)                       # the new rows were written
-    # the matrix-core kernel (>= 4 query heads per kv head) WITH head norms is declined: None, nothing written
-    big = _randn(2, (8 + 4) * 128, dtype=dtype, seed=55).to(DEV)
-    one = torch.ones(128, dtype=dtype, device=DEV)
-    none = H.rope_paged_decode(big[:, :8 * 128].view(2, 8, 128), big[:, 8 * 128:10 * 128].view(2, 2, 128),
-                               big[:, 10 * 128:].view(2, 2, 128), pos[:2].to(DEV), cos[:, :64], sin[:, :64], one, one,
+    # more than 16 query heads per kv head (two head chunks) is declined: None, nothing written
+    big = _randn(2, (40 + 4) * 128, dtype=dtype, seed=55).to(DEV)
+    none = H.rope_paged_decode(big[:, :40 * 128].view(2, 40, 128), big[:, 40 * 128:42 * 128].view(2, 2, 128),
+                               big[:, 42 * 128:].view(2, 2, 128), pos[:2].to(DEV), cos[:, :64], sin[:, :64], None, None,
                                1e-6, slots[:2].to(DEV), *[_randn(40, 64, 2, 128, dtype=dtype, seed=1).to(DEV)] * 2,
                                table[:2].to(DEV), ctx[:2].to(DEV), scale)
     assert none is None
