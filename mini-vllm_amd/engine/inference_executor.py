@@ -175,11 +175,18 @@ class InferenceExecutor:
         for p in self.model.parameters():
             p.requires_grad = False
 
+    @staticmethod
+    def warmup_sequences(max_num_batched_tokens: int, max_num_seqs: int, max_model_len: int) -> int:
+        """The reference's count (inference_executor.py:373-410), but never 0: with a token budget below
+        max_model_len / 2 (chunked prefill: 16384 against 40960) its quotient is 0 and the warm-up -- and the
+        library set-up behind it -- would be skipped although the 16-token dummies always fit the budget."""
+        return max(1, min(max_num_batched_tokens // max(max_model_len // 2, 1), max_num_seqs, 2))
+
     def _warmup_model(self, max_num_batched_tokens: int, max_num_seqs: int) -> None:
         """2 x 16-token dummy prefill + one decode with EMPTY block tables
         (inference_executor.py:373-410): exercises the no-slot / zero-column paths."""
         mml = self.config.max_model_len
-        n = min(max_num_batched_tokens // max(mml // 2, 1), max_num_seqs, 2)
+        n = self.warmup_sequences(max_num_batched_tokens, max_num_seqs, mml)
         dummy = [Sequence([0] * min(16, mml), block_size=self.block_size) for _ in range(n)]
         if not dummy:
             return

@@ -94,9 +94,11 @@ class Scheduler:
         BEFORE the decode rows are scheduled (that step takes blocks); when the head of the queue only fits alone,
         the step is the reference's: that prompt first, by itself."""
         room = self.max_num_batched_tokens - rows
+        if rows >= self.max_num_seqs:          # the step's rows (decode rows + prompts) never exceed max_num_seqs:
+            return False                       # a chunk in flight waits for a step of its own like a new prompt does
         if self.prefilling is not None:
             return room >= self.block_manager.block_size
-        if not self.waiting or rows >= self.max_num_seqs:
+        if not self.waiting:
             return False
         head = self.waiting[0]
         if not self.block_manager.can_allocate(head):

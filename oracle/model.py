@@ -71,6 +71,28 @@ class OracleModel:
             w[name + ".weight"] = rnd(out_f, in_f)
             if bias:
                 w[name + ".bias"] = torch.zeros(out_f, dtype=dtype)
+        if c.model_type == "opt":          # HF OPT names (minivllm/models/opt.py:84-279): biased projections, LayerNorm
+            pre = "model.decoder."
+            w[pre + "embed_tokens.weight"] = rnd(c.vocab_size, getattr(c, "word_embed_proj_dim", h))
+            w[pre + "embed_positions.weight"] = rnd(c.max_position_embeddings + 2, h)
+            if getattr(c, "word_embed_proj_dim", h) != h:
+                lin(pre + "project_in", h, c.word_embed_proj_dim)
+                lin(pre + "project_out", c.word_embed_proj_dim, h)
+
+            def norm(name):
+                w[name + ".weight"] = torch.ones(h, dtype=dtype)
+                w[name + ".bias"] = torch.zeros(h, dtype=dtype)
+            for i in range(c.num_hidden_layers):
+                p = f"{pre}layers.{i}."
+                for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                    lin(p + "self_attn." + n, h, h, bias=True)
+                lin(p + "fc1", c.ffn_dim, h, bias=True)
+                lin(p + "fc2", h, c.ffn_dim, bias=True)
+                norm(p + "self_attn_layer_norm")
+                norm(p + "final_layer_norm")
+            if getattr(c, "do_layer_norm_before", True):
+                norm(pre + "final_layer_norm")
+            return cls(config, w, dtype=dtype, **kw)
         assert c.model_type in ("qwen2", "qwen3")
         bias = getattr(c, "attention_bias", c.model_type == "qwen2")
         w["model.embed_tokens.weight"] = rnd(c.vocab_size, h)

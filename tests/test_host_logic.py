@@ -390,3 +390,39 @@ def test_chunked_prefill_config_gate(tmp_path):
         Config(str(tmp_path), max_num_batched_tokens=1024, max_model_len=4096)
     cfg = Config(str(tmp_path), max_num_batched_tokens=1024, max_model_len=4096, enable_chunked_prefill=True)
     assert cfg.max_model_len == 4096
+
+
+def test_mixed_chunked_steps_never_exceed_max_num_seqs():
+    """A chunk in flight must not ride on a step that already holds max_num_seqs decode rows (the staging buffers,
+    the sampler planes and the graph buckets are sized for max_num_seqs rows): bs=8, 32-token budget, max_num_seqs=4,
+    four running sequences and a 100-token prompt — the chunks then run alone, like the first one does."""
+    cfg = SimpleNamespace(max_num_seqs=4, max_num_batched_tokens=32, eos=-1, num_kvcache_blocks=64,
+                          kvcache_block_size=8, max_model_len=256, enable_chunked_prefill=True,
+                          enable_mixed_batches=True)
+    sched = Scheduler(cfg)
+    sp = SamplingParams(max_tokens=64, ignore_eos=True)
+    for i in range(4):
+        sched.add(Sequence([i + 1, i + 2, i + 3], sp, block_size=8))
+    batch, is_prefill = sched.schedule()
+    assert is_prefill and len(batch) == 4
+    sched.postprocess(batch, [7] * 4)
+    long_seq = Sequence(list(range(100, 200)), SamplingParams(max_tokens=2, ignore_eos=True), block_size=8)
+    sched.add(long_seq)
+    sizes = []
+    for _ in range(12):
+        batch, is_prefill = sched.schedule()
+        sizes.append(len(batch))
+        assert len(batch) <= cfg.max_num_seqs, sizes
+        sched.postprocess(batch, [9] * len(batch))
+        if long_seq.num_completion_tokens:
+            break
+    assert long_seq.num_completion_tokens == 1 and sched.prefilling is None
+    assert 1 in sizes                                          # the chunks ran in steps of their own
+
+
+def test_warmup_runs_when_the_token_budget_is_below_half_the_model_length():
+    from minivllm_amd.engine.inference_executor import InferenceExecutor
+
+    assert InferenceExecutor.warmup_sequences(16384, 256, 40960) == 1     # chunked prefill as intended: was 0
+    assert InferenceExecutor.warmup_sequences(16384, 256, 4096) == 2      # the reference's count where it is >= 1
+    assert InferenceExecutor.warmup_sequences(16384, 1, 4096) == 1
