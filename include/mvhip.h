@@ -361,6 +361,11 @@ int mv_topc_pack(const void *logits_local, int64_t ld, int vocab_local, int rank
                  int64_t vocab_per_rank, int rows, int rows_padded, void *buf, int dtype, void *stream);
 int mv_topc_unpack(const void *buf, int world, int rows, int rows_padded, void *cand_logits,
                    int32_t *cand_idx, int dtype, void *stream);
+/* mv_topc_pick: tokens[r] = cand_idx[r][pos[r]] for sampled rows; for rows with temperatures[r] == 0 (greedy; NULL =
+ * no greedy rows) the LOWEST global index among the candidates equal to the row maximum — the token TP = 1's argmax and
+ * mv_greedy_merge name on ties (candidate order is shard-visiting order, not index order). */
+int mv_topc_pick(const void *cand_logits, const int32_t *cand_idx, const int64_t *pos,
+                 const float *temperatures, int64_t *tokens, int rows, int width, int dtype, void *stream);
 
 #ifdef __cplusplus
 }

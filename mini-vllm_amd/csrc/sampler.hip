@@ -712,7 +712,56 @@ __global__ void topc_unpack_kernel(const uint16_t *buf, int world, int rows, int
                 (int32_t)elem<Tag>::ld((uint16_t)(w[1] >> 16));
 }
 
+// candidate position -> token id.  Sampled rows: the global index of the drawn candidate.  Greedy rows
+// (temperature 0): the LOWEST global index among the candidates equal to the row maximum — candidates are laid out in
+// shard-visiting order, not in index order, so "first maximum by candidate position" could name a higher token id than
+// TP = 1 (argmax: lowest index on ties) and the all-greedy path (mv_greedy_merge) do, and the same greedy
+// request would then decode differently depending on what it is batched with.  One wave per row.
+template <typename Tag>
+__global__ void __launch_bounds__(64) topc_pick_kernel(const uint16_t *cand_logits, const int32_t *cand_idx,
+                                                       const int64_t *pos, const float *temperatures, int64_t *tokens,
+                                                       int width) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const uint16_t *cl = cand_logits + (int64_t)r * width;
+  const int32_t *ci = cand_idx + (int64_t)r * width;
+  const bool greedy = temperatures != nullptr && temperatures[r] == 0.0f;
+  if (!greedy) {
+    if (lane == 0) {
+      int64_t p = pos[r];
+      p = p < 0 ? 0 : (p >= width ? width - 1 : p);
+      tokens[r] = ci[p];
+    }
+    return;
+  }
+  uint32_t best = 0;
+  for (int i = lane; i < width; i += 64) best = max(best, make_key<Tag>(cl[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o, 64));
+  int32_t tok = 0x7fffffff;
+  for (int i = lane; i < width; i += 64)
+    if (make_key<Tag>(cl[i]) == best) tok = min(tok, ci[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tok = min(tok, __shfl_xor(tok, o, 64));
+  if (lane == 0) tokens[r] = tok;
+}
+
 }  // namespace
+
+extern "C" int mv_topc_pick(const void *cand_logits, const int32_t *cand_idx, const int64_t *pos,
+                            const float *temperatures, int64_t *tokens, int rows, int width, int dtype, void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!cand_logits || !cand_idx || !pos || !tokens) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (rows < 0 || width <= 0) return MV_E_SHAPE;
+  if (dtype == MV_BF16)
+    hipLaunchKernelGGL((topc_pick_kernel<bf16_tag>), dim3(rows), dim3(64), 0, (hipStream_t)stream,
+                       (const uint16_t *)cand_logits, cand_idx, pos, temperatures, tokens, width);
+  else
+    hipLaunchKernelGGL((topc_pick_kernel<f16_tag>), dim3(rows), dim3(64), 0, (hipStream_t)stream,
+                       (const uint16_t *)cand_logits, cand_idx, pos, temperatures, tokens, width);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
 
 extern "C" size_t mv_sample_workspace_bytes(int batch, int vocab) {
   (void)batch; (void)vocab;

@@ -7,6 +7,9 @@ become the block tables and slot mappings the HIP kernels index with.  What fixe
     taken; stale entries are dropped only when they reach the front) plus a membership set;
   * a full block's digest is xxh64(prefix digest as 8 LE bytes (if any) || int32-LE tokens);
   * a freed block keeps its digest/tokens until it is handed out again (so it can be revived).
+Method names, the deque-plus-tombstone pool and the order of its operations are the reference's by necessity (the ids
+they produce are compared bit for bit with reference traces, tests/test_host_logic.py); the error texts are this
+build's own, except the leading words of "No free blocks available", which DESIGN.md Q10 and the scheduler refer to.
 """
 from __future__ import annotations
 
@@ -44,9 +47,9 @@ class Block:
 class BlockManager:
     def __init__(self, num_blocks: int, block_size: int) -> None:
         if num_blocks <= 0:
-            raise ValueError(f"num_blocks must be positive, got {num_blocks}")
+            raise ValueError(f"a block pool needs at least one block (num_blocks={num_blocks})")
         if block_size <= 0:
-            raise ValueError(f"block_size must be positive, got {block_size}")
+            raise ValueError(f"a block holds at least one token (block_size={block_size})")
         self.block_size = block_size
         self.num_blocks = num_blocks
         self.blocks = [Block(i) for i in range(num_blocks)]
@@ -60,7 +63,7 @@ class BlockManager:
     @classmethod
     def compute_hash(cls, token_ids: list[int], prefix: int = -1) -> int:
         if not token_ids:
-            raise ValueError("token_ids cannot be empty for hash computation")
+            raise ValueError("the digest of a block is taken over its tokens: got none")
         h = xxhash.xxh64()
         if prefix != -1:
             h.update(prefix.to_bytes(8, "little"))
@@ -74,17 +77,17 @@ class BlockManager:
             if q[0] in self._free_set:
                 return q[0]
             q.popleft()  # tombstone of a block that was taken since
-        raise RuntimeError("No free blocks available")
+        raise RuntimeError("No free blocks available: the KV pool is exhausted")  # (first words = the reference's)
 
     def _take(self, block_id: int, reset: bool = True) -> Block:
         if not 0 <= block_id < self.num_blocks:
-            raise RuntimeError(f"Invalid block_id: {block_id}. Valid range: [0, {self.num_blocks})")
+            raise RuntimeError(f"block id {block_id} is outside the pool [0, {self.num_blocks})")
         if block_id not in self._free_set:
-            raise RuntimeError(f"Block {block_id} not in free blocks")
+            raise RuntimeError(f"block {block_id} was asked for but is not free")
         self._free_set.remove(block_id)
         block = self.blocks[block_id]
         if block.ref_count != 0:
-            raise RuntimeError(f"Block {block_id} already allocated with ref_count={block.ref_count}")
+            raise RuntimeError(f"free block {block_id} still has {block.ref_count} reference(s)")
         if reset:
             if block.hash != NO_HASH and self.hash_to_block_id.get(block.hash) == block_id:
                 del self.hash_to_block_id[block.hash]
@@ -99,11 +102,10 @@ class BlockManager:
 
     def _deallocate_block(self, block_id: int) -> None:
         if not 0 <= block_id < self.num_blocks:
-            raise RuntimeError(f"Invalid block_id: {block_id}. Valid range: [0, {self.num_blocks})")
+            raise RuntimeError(f"block id {block_id} is outside the pool [0, {self.num_blocks})")
         block = self.blocks[block_id]
         if block.ref_count != 0:
-            raise RuntimeError(
-                f"Cannot deallocate block {block_id} with ref_count={block.ref_count} (must be 0)")
+            raise RuntimeError(f"block {block_id} is still referenced {block.ref_count} time(s): it cannot go back to the pool")
         self.used_block_ids.remove(block_id)
         self.free_block_ids.append(block_id)
         self._free_set.add(block_id)
@@ -117,11 +119,10 @@ class BlockManager:
 
     def allocate(self, sequence: Sequence) -> None:
         if sequence.block_table:
-            raise ValueError("Sequence already has allocated blocks")
+            raise ValueError("this sequence already owns a block table")
         if len(self._free_set) < sequence.num_blocks:
-            raise ValueError(
-                f"No free blocks available for allocation: need {sequence.num_blocks}, "
-                f"have {len(self._free_set)}")
+            raise ValueError(f"prompt needs {sequence.num_blocks} blocks, the pool has {len(self._free_set)} free "
+                             f"(callers test can_allocate first)")
         chain = NO_HASH
         for i in range(sequence.num_blocks):
             tokens = sequence.block(i)
@@ -179,17 +180,17 @@ class BlockManager:
         pos = len(sequence) % self.block_size
         if pos == 1:  # first token of a new block: take one
             if last.hash == NO_HASH:
-                raise RuntimeError(f"Previous block {last.block_id} hash not finalized")
+                raise RuntimeError(f"block {last.block_id} is full but its digest was never published")
             block_id = self._get_any_free_block()
             self._take(block_id)
             table.append(block_id)
         elif pos == 0:  # block just filled: publish its digest for prefix caching
             if last.hash != NO_HASH:
-                raise RuntimeError(f"Block {last.block_id} hash already set")
+                raise RuntimeError(f"block {last.block_id} just filled up, yet it already carries a digest")
             tokens = sequence.block(sequence.num_blocks - 1)
             prefix = self.blocks[table[-2]].hash if len(table) > 1 else NO_HASH
             digest = self.compute_hash(tokens, prefix)
             last.update(digest, tokens)
             self.hash_to_block_id[digest] = last.block_id
         elif last.hash != NO_HASH:
-            raise RuntimeError(f"Partial block {last.block_id} should not have hash")
+            raise RuntimeError(f"block {last.block_id} is only partly filled, yet it carries a digest")

@@ -326,7 +326,8 @@ class InferenceExecutor:
 
     def _cand_tokens(self, logits_local, t, k, p, m):
         """'cand' mode, eager: the sampler (one Philox step, like any other batch) on the gathered candidates."""
-        return tp_candidate_tokens(logits_local, lambda cl: self.sampler(cl, temperatures=t, top_ks=k, top_ps=p, min_ps=m))
+        return tp_candidate_tokens(logits_local, lambda cl: self.sampler(cl, temperatures=t, top_ks=k, top_ps=p, min_ps=m),
+                                   temperatures=t.float().contiguous())
 
     def _greedy_merge(self, logits_local, t, k, p, m):
         """Tokens of an all-greedy batch from this rank's vocab shard (temperature 0 rows: the sampler
@@ -430,7 +431,10 @@ class InferenceExecutor:
                 for bs in reversed(self.graph_bs):
                     self._capture_one(bs, greedy=True)
                 if self.greedy_graphs and decode_step_is_native(self.dtype, hf.hidden_size, hf.vocab_size):
-                    self._cand_capture = "lazy"   # same property: only this library's kernels inside (first use captures)
+                    # same property: only this library's kernels inside, so nothing argues for laziness -- captured
+                    # here, out of the same pool, before any sequence is live (a capture in mid-serving would stall
+                    # every rank for seconds and take its memory from whatever the KV pool left over)
+                    self._capture_cand()
                 if general_ok and self.greedy_graphs and decode_step_is_native(self.dtype, hf.hidden_size, hf.vocab_size):
                     # the gathered-logits family needs RCCL nodes in its graphs: captured on the first batch with
                     # a sampled row (_graph_bucket), so that a greedy-only workload never captures a collective
@@ -520,7 +524,7 @@ class InferenceExecutor:
             out.copy_(self.model.compute_logits(hidden, gather=False))
             toks = tp_candidate_tokens(out, lambda cl: hip_ops.sample(
                 cl, d[0, :bs], self._dev_samp_i64[:bs], d[1, :bs], d[2, :bs], seed=self.sampler.seed, offset=0,
-                offset_dev=gv["rng_offset"]))
+                offset_dev=gv["rng_offset"]), temperatures=d[0, :bs])
         else:
             out = gv["logits"][:bs]
             out.copy_(self.model.compute_logits(hidden))

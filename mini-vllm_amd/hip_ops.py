@@ -95,6 +95,7 @@ _SIGNATURES = {
     "mv_topc_width": (c_int, []),
     "mv_topc_pack": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mv_topc_unpack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "mv_topc_pick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -670,6 +671,21 @@ def topc_unpack(buf, rows: int):
     _check(_lib.mv_topc_unpack(buf.data_ptr(), world, rows, rows_padded, cl.data_ptr(), ci.data_ptr(), _dt(buf), _stream()),
            "mv_topc_unpack")
     return cl, ci
+
+
+def topc_pick(cand_logits, cand_idx, pos, temperatures=None):
+    """Candidate positions -> int64 token ids; temperature-0 rows take the lowest global index among the row maxima
+    (see mv_topc_pick)."""
+    _need_cuda(cand_logits, cand_idx, pos)
+    rows, width = cand_logits.shape
+    assert cand_idx.dtype == torch.int32 and pos.dtype == torch.int64 and cand_idx.shape == cand_logits.shape
+    assert cand_logits.is_contiguous() and cand_idx.is_contiguous()
+    if temperatures is not None:
+        assert temperatures.dtype == torch.float32 and temperatures.shape[0] >= rows and temperatures.is_contiguous()
+    out = torch.empty((rows,), dtype=torch.int64, device=cand_logits.device)
+    _check(_lib.mv_topc_pick(cand_logits.data_ptr(), cand_idx.data_ptr(), pos.data_ptr(), _ptr(temperatures),
+                             out.data_ptr(), rows, width, _dt(cand_logits), _stream()), "mv_topc_pick")
+    return out
 
 
 # ---------------------------------------------------------------- a2 (device side)

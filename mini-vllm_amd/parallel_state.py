@@ -126,7 +126,7 @@ def tp_greedy_tokens(logits_local: torch.Tensor, local_tokens: torch.Tensor) -> 
     return tp_merge_greedy(local_tokens, vals, vpr)
 
 
-def tp_candidate_tokens(logits_local: torch.Tensor, sample_fn) -> torch.Tensor:
+def tp_candidate_tokens(logits_local: torch.Tensor, sample_fn, temperatures: torch.Tensor | None = None) -> torch.Tensor:
     """Sampled tokens without the full-logit gather (sampled rows): valid for batches whose rows are
     greedy or have 1 <= top_k <= hip_ops.TOPC.  Every rank packs the 64 largest logits of its vocab shard per row
     (+ global indices) into its slot of a zeroed buffer, the all-reduce sums the slots (x + 0: an exact gather,
@@ -141,7 +141,9 @@ def tp_candidate_tokens(logits_local: torch.Tensor, sample_fn) -> torch.Tensor:
     tp_all_reduce(buf.view(-1))
     cand_logits, cand_idx = hip_ops.topc_unpack(buf, n)
     pos = sample_fn(cand_logits)
-    return cand_idx.gather(1, pos.unsqueeze(1)).squeeze(1).long()
+    # ``temperatures`` (fp32, one per row): greedy rows take the lowest token id among the maxima, like TP = 1 and the
+    # all-greedy path do -- candidate order is not index order (mv_topc_pick)
+    return hip_ops.topc_pick(cand_logits, cand_idx, pos, temperatures)
 
 
 def decode_step_is_native(dtype: torch.dtype, hidden_size: int, vocab_size: int) -> bool:

@@ -334,8 +334,8 @@ def test_config5_per_gpu_layer_shape_qwen2_72b_tp8(tmp_path):
     heads / 1 kv head of 128, intermediate 29568 / 8 = 3696, qkv bias — as a 2-layer model (no collectives: what a
     rank computes between its all-reduces), bf16, against the fp32 oracle on the same seeded weights: prefill of
     three prompts, then decode steps at a batch that takes the decode-batch projection kernels (40 rows; down_proj's
-    K = 3696 is not a multiple of 64 and stays on the library GEMM).  Bound: 2.5 % of the logit scale (bf16 through
-    two 8192-wide layers against fp32 math; the measured error is printed)."""
+    K = 3696 is not a multiple of 64 and stays on the library GEMM).  Bound: max(1e-3 x scale, 1.5 x the error of the
+    oracle's OWN bf16 run against its fp32 run) — the bar of the other end-to-end tests; both errors are printed."""
     import golden_inputs as GI
     from oracle.model import OracleModel
 
@@ -374,6 +374,7 @@ def test_config5_per_gpu_layer_shape_qwen2_72b_tp8(tmp_path):
     ex = InferenceExecutor(cfg, model, torch.device(DEV))
     ex._allocate_kv_cache(); ex._initialize_sampler(); ex._optimize_model()
     ref = OracleModel(cfg_d, {k: v.float() for k, v in hfw.items()}, torch.float32, num_blocks=3 * nseq)
+    ref16 = OracleModel(cfg_d, {k: v.float() for k, v in hfw.items()}, torch.bfloat16, num_blocks=3 * nseq)
     g = torch.Generator().manual_seed(0)
     greedy = SamplingParams(temperature=0.0, max_tokens=64, ignore_eos=True)
     seqs = [Sequence(torch.randint(0, 2048, (int(n),), generator=g).tolist(), greedy, block_size=64)
@@ -381,24 +382,30 @@ def test_config5_per_gpu_layer_shape_qwen2_72b_tp8(tmp_path):
     bm, ib = BlockManager(3 * nseq, 64), InputBuilder(64, 64, 192, 4096)
     for s in seqs:
         bm.allocate(s)
-    worst = 0.0
+    worst = worst_noise = 0.0
     for step in range(3):
         prefill = step == 0
         inp = ib.prefill(seqs) if prefill else ib.decode(seqs)
         meta = dict(is_prefill=prefill, slot_mapping=inp.slot_mapping, block_tables=inp.block_tables,
                     cu_q=inp.cum_seqlens_q, cu_k=inp.cum_seqlens_k, context_lens=inp.context_lens)
         want = ref.forward_logits(inp.input_ids.clone(), inp.positions.clone(), meta).float()
+        # the noise floor of bf16 on THIS model: the oracle's own bf16 run (reference op order and rounding points,
+        # same tokens, its own bf16 KV cache) against its fp32 run
+        noise = (ref16.forward_logits(inp.input_ids.clone(), inp.positions.clone(), meta).float() - want).abs().max().item()
         got, _ = ex.execute_batch(seqs, prefill=prefill)
         got = got.float().cpu()
         scale = want.abs().max().item()
         err = (got - want).abs().max().item()
         worst = max(worst, err / scale)
-        assert err <= 0.025 * scale, f"step {step}: err {err:.4f} scale {scale:.3f}"
+        worst_noise = max(worst_noise, noise / scale)
+        # the bar of every other e2e test: max(1e-3 * scale, 1.5 x the bf16 noise of the eager op order)
+        assert err <= max(1e-3 * scale, 1.5 * noise), f"step {step}: err {err:.4f} noise {noise:.4f} scale {scale:.3f}"
         assert torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item() > 0.9995
         for s, t in zip(seqs, want.argmax(-1).tolist()):
             s.append_token(int(t))
             bm.may_append(s)
-    print(f"\nconfig 5 per-GPU shard (hidden 8192, 8/1 heads, inter 3696), bf16 vs fp32 oracle: worst error {worst:.4%} of the logit scale")
+    print(f"\nconfig 5 per-GPU shard (hidden 8192, 8/1 heads, inter 3696), bf16 vs fp32 oracle: worst error {worst:.4%} of the "
+          f"logit scale (the oracle's own bf16 run: {worst_noise:.4%})")
 
 
 def test_chunked_prefill_equals_one_shot_prefill(golden_dir, tmp_path):
@@ -436,6 +443,68 @@ def test_chunked_prefill_equals_one_shot_prefill(golden_dir, tmp_path):
     assert [x[1] for x in chunked][:3] == [[128], [128], [44]]            # the long prompt: three chunks, alone
     # last-token logits of the long prompt: final chunk vs the one-shot prefill row of the same sequence
     torch.testing.assert_close(chunked[2][2][0], one_shot[0][2][0], rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_chunked_prefill_matches_the_reference_one_shot_logits(golden_dir, tmp_path, dtype):
+    """An INDEPENDENT pin for the chunked / paged form of the prefill kernel (the self-consistency test above would pass a
+    bug shared by both runs): the golden prompts (70, 5 and 65 tokens) prefilled with a 64-token budget — the 70- and
+    65-token prompts in two chunks each, the second chunk attending the first through the paged cache — must give the
+    REFERENCE's one-shot prefill logits (tests/golden/e2e_qwen3.npz, recorded from the reference in fp32 and bf16),
+    and the forced decode steps behind them the reference's decode logits."""
+    from minivllm_amd.engine.scheduler import Scheduler
+    from minivllm_amd.engine.sequence import Sequence
+    from minivllm_amd.sampling_params import SamplingParams
+
+    z = _load(golden_dir, "qwen3")
+    cfg, _, ex = _build(tmp_path, z, dtype)
+    cfg.max_num_batched_tokens, cfg.enable_chunked_prefill = 64, True
+    sched = Scheduler(cfg)
+    sp = SamplingParams(temperature=0.0, max_tokens=64, ignore_eos=True)
+    seqs = [Sequence(p, sp, block_size=64) for p in _prompts(z)]
+    for s in seqs:
+        sched.add(s)
+    forced = z["forced_tokens"]
+    rows, chunks = {}, []
+    while sched.waiting or sched.prefilling is not None:
+        batch, is_prefill = sched.schedule()
+        assert is_prefill
+        chunks.append([s.prefill_stop - s.num_cached_tokens for s in batch])
+        logits, _ = ex.execute_batch(batch, prefill=True)
+        logits = logits.float().cpu()
+        toks = []
+        for i, s in enumerate(batch):
+            if s.prefill_end is None:                      # a last (or only) chunk: its row is the prompt's logits
+                rows[seqs.index(s)] = logits[i]
+            toks.append(int(forced[0][seqs.index(s)]))
+        sched.postprocess(batch, toks)
+    assert chunks == [[64], [6], [5], [64], [1]]            # 70 = 64 + 6, 5, 65 = 64 + 1
+    got = torch.stack([rows[i] for i in range(3)])
+    want32, want16 = torch.from_numpy(z["f32_prefill_logits"]), torch.from_numpy(z["bf16_prefill_logits"])
+    scale = want32.abs().max().item()
+    err = (got - want32).abs().max().item()
+    if dtype == torch.float32:
+        assert err <= 2e-4 * scale, f"chunked prefill vs reference fp32: {err:.3e}"
+        assert got.argmax(-1).tolist() == want32.argmax(-1).tolist()
+    else:
+        noise = (want16 - want32).abs().max().item()
+        assert err <= max(1e-3 * scale, 1.5 * noise), f"chunked prefill vs reference: err {err:.3e} noise {noise:.3e}"
+    # the decode steps behind the chunked prefill read the K/V rows the chunks stored
+    by_id = {s.seq_id: i for i, s in enumerate(seqs)}
+    for step in range(2):
+        batch, is_prefill = sched.schedule()
+        assert not is_prefill and len(batch) == 3
+        logits, _ = ex.execute_batch(batch, prefill=False)
+        order = [by_id[s.seq_id] for s in batch]
+        got = logits.float().cpu()
+        want = torch.from_numpy(z[f"f32_decode_logits_{step}"])[order]
+        err = (got - want).abs().max().item()
+        if dtype == torch.float32:
+            assert err <= 2e-4 * scale, f"decode step {step} after chunked prefill: {err:.3e}"
+        else:
+            noise = (torch.from_numpy(z[f"bf16_decode_logits_{step}"])[order] - want).abs().max().item()
+            assert err <= max(1e-3 * scale, 1.5 * noise)
+        sched.postprocess(batch, [int(forced[step + 1][i]) for i in order])
 
 
 def test_mixed_batches_equal_separate_steps(golden_dir, tmp_path):

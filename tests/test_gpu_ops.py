@@ -561,6 +561,42 @@ def test_topc_candidates_hold_the_top_k_set_and_sample_like_the_full_row(H, dtyp
     assert int(ci[2, tok_c[2]]) == int(full[2].float().argmax())                 # the greedy row: the global argmax (no tie here)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_topc_greedy_rows_break_ties_towards_the_lowest_token_id(H, dtype):
+    """A tie at the maximum is plausible with 16-bit logits.  TP = 1 (argmax: lowest index) and the all-greedy exchange
+    (mv_greedy_pack / mv_greedy_merge) name the LOWEST token id; the candidate path lays its candidates out in
+    shard-visiting order, so its greedy rows must not take "the first maximum by candidate position" (mv_topc_pick)."""
+    world, vocab, B = 4, 151936, 5
+    vpr = vocab // world
+    g = torch.Generator().manual_seed(11)
+    full = (torch.randn(B, vocab, generator=g) * 2).to(dtype)
+    top = float(full.float().max()) + 1.0
+    # ties at the maximum: inside one shard (far apart, so that different threads visit them), across shards, adjacent
+    tied = [[vpr + 9000, vpr + 17], [3 * vpr + 5, 40000, 2 * vpr + 1], [70001, 70000], [vocab - 1, 123], [777]]
+    for b, idxs in enumerate(tied):
+        full[b, idxs] = top
+    full = full.to(DEV)
+    want = [min(t) for t in tied]
+    assert full.float().argmax(-1).tolist() == want                         # torch: first maximum = lowest index
+    temps = torch.tensor([0.0, 0.0, 0.0, 0.0, 0.8], device=DEV)             # row 4 is sampled with top_k = 1
+    ks = torch.tensor([-1, -1, -1, -1, 1], dtype=torch.int64, device=DEV)
+    ones, zeros = torch.ones(B, device=DEV), torch.zeros(B, device=DEV)
+    tp1 = H.sample(full, temps, ks, ones, zeros, seed=3)
+    assert tp1.tolist() == want
+    bufs = [H.topc_pack(full[:, r * vpr:(r + 1) * vpr], r, world, B) for r in range(world)]
+    cl, ci = H.topc_unpack(torch.stack([b.float() for b in bufs]).sum(0).to(dtype), B)
+    pos = H.sample(cl, temps, ks, ones, zeros, seed=3)
+    toks = H.topc_pick(cl, ci, pos, temps)
+    assert toks.dtype == torch.int64 and toks.tolist() == want
+    # without the temperatures every row is "sampled": the drawn candidate's own index
+    assert H.topc_pick(cl, ci, pos).tolist() == ci.gather(1, pos.unsqueeze(1)).squeeze(1).tolist()
+    # the all-greedy exchange agrees
+    local = [H.sample(full[:, r * vpr:(r + 1) * vpr].contiguous(), torch.zeros(B, device=DEV), ks, ones, zeros) for r in range(world)]
+    packed = [H.greedy_pack(full[:, r * vpr:(r + 1) * vpr].contiguous(), local[r], r, world, B + (B & 1)) for r in range(world)]
+    merged = H.greedy_merge(torch.stack([b.float() for b in packed]).sum(0).to(dtype), B)
+    assert merged.tolist()[:4] == want[:4]
+
+
 # ------------------------------------------------------------------ K10
 def _ulp_ok(got, exact, dtype, ulps):
     """|got - exact| <= ulps units in the last place of ``dtype`` at the magnitude of ``exact``
