@@ -149,7 +149,7 @@ class QwenAttention(nn.Module):
         ctx = get_context()
         attn = self.attn
         has_cache = attn.k_cache.numel() > 0
-        cos, sin = self.rotary_emb._tables(qkv.device)
+        cos, sin = self.rotary_emb._tables(qkv.device, qkv.dtype)
         if (ROPE_FOLD and t <= ROPE_FOLD_MAX_ROWS and has_cache and not ctx.is_prefill and ctx.slot_mapping is not None
                 and ctx.block_tables is not None and ctx.context_lens is not None):
             # decode step: head norms, RoPE and the K/V store ride in the attention launch (mv_rope_paged_decode)

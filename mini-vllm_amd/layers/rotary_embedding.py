@@ -43,22 +43,28 @@ class RotaryEmbedding(nn.Module):
         cos, sin = build_cos_sin(rotary_dim, max_position_embeddings, base, rope_scaling)
         self.register_buffer("cos_cache", cos, persistent=False)  # [max_pos, D/2] fp32
         self.register_buffer("sin_cache", sin, persistent=False)
+        # the fp32 originals, as plain attributes: ``model.to(dtype)`` rounds the BUFFERS in place, and this module
+        # is shared through ``get_rope``'s cache (like the reference's) -- by every layer of a model, but also by a
+        # second model of another dtype built later in the same process, which must not inherit the first one's
+        # rounded tables (found by an fp32 test that ran behind bf16 tests: 3e-3 of the logit scale)
+        self._cos32, self._sin32 = cos.clone(), sin.clone()
+        self._dev_tables: dict = {}
 
-    def _tables(self, device):
-        """fp32 device tables for the kernel.  ``model.to(dtype)`` casts the buffers like it does
-        in the reference (whose bf16 runs therefore rotate with bf16-ROUNDED cos/sin, as HF does);
-        the rounded values are widened back to fp32 here, so both behaviours are reproduced."""
-        src = self.cos_cache
-        cached = getattr(self, "_fp32_tables", None)
-        if cached is None or cached[0] is not src or cached[1].device != device:
-            cached = (src, self.cos_cache.to(device=device, dtype=torch.float32).contiguous(),
-                      self.sin_cache.to(device=device, dtype=torch.float32).contiguous())
-            self._fp32_tables = cached
-        return cached[1], cached[2]
+    def _tables(self, device, dtype: torch.dtype | None = None):
+        """fp32 device tables for the kernel.  The reference's ``model.to(dtype)`` casts its cos/sin buffers, so its
+        bf16 runs rotate with bf16-ROUNDED cos/sin (as HF does): ``dtype`` = the model / activation dtype reproduces
+        that (rounded through ``dtype``, widened back to fp32); None = the unrounded fp32 tables."""
+        dtype = dtype or torch.float32
+        key = (str(device), dtype)
+        hit = self._dev_tables.get(key)
+        if hit is None:
+            hit = tuple(t.to(dtype).to(device=device, dtype=torch.float32).contiguous() for t in (self._cos32, self._sin32))
+            self._dev_tables[key] = hit
+        return hit
 
     def forward(self, positions, query, key):
         """query [T,H,D], key [T,Hkv,D] -> rotated copies."""
-        cos, sin = self._tables(query.device)
+        cos, sin = self._tables(query.device, query.dtype)
         return hip_ops.rope_qk_store(query, key, None, positions, cos, sin)
 
 
