@@ -55,6 +55,7 @@ struct MidParams {
   int n_tiles, m_tiles;
   int kb_per_split;   // 64-element k-blocks per K split (blockIdx.y)
   int krot;           // rotate the K loop start per workgroup
+  int ablate;         // bench only: bit 0 = no x DMA, bit 1 = no W DMA (the LDS slots keep whatever they hold)
 };
 
 template <int N>
@@ -117,6 +118,7 @@ __global__ void __launch_bounds__((WM * WN + NLX + NLW) * 64) linear_mid_m_kerne
         src[j] = (const T *)p.x + (int64_t)m * p.x_stride + (((lane & 7) ^ (row & 7)) << 3);
       }
       auto issue = [&](int i, int slot) {
+        if (p.ablate & 1) return;
         char *dst = xl + slot * XS + lw * 1024;
         const int koff = kb_of(i) * 64;
 #pragma unroll
@@ -159,6 +161,7 @@ __global__ void __launch_bounds__((WM * WN + NLX + NLW) * 64) linear_mid_m_kerne
       // 4 MiB L2 and come from the Infinity Cache; launch times unchanged, profiles/r02_pmc_mid_m.json)
       const bool once = p.m_tiles == 1;
       auto issue = [&](int i, int slot) {
+        if (p.ablate & 2) return;
         char *dst = wl + slot * WS + lw2 * 1024;
         const int koff = kb_of(i) * 1024;   // 2 fragments of 512 elements per k-block
         if (once) {
@@ -186,6 +189,14 @@ __global__ void __launch_bounds__((WM * WN + NLX + NLW) * 64) linear_mid_m_kerne
   }
 
   // ================================ compute waves ================================
+  // bench only (ablate bit 2): shader-clock and wall-clock stamps around the K loop of wave 0 -> the clock the chip
+  // holds inside this kernel = d(s_memtime) / d(s_memrealtime) x 100 MHz; written to the buffer passed as `bias`
+  uint64_t st_c0 = 0, st_r0 = 0;
+  const bool stamp = (p.ablate & 4) && wave == 0;
+  if (stamp) {
+    st_c0 = __builtin_amdgcn_s_memtime();
+    st_r0 = __builtin_amdgcn_s_memrealtime();
+  }
   const int r16 = lane & 15, g = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
   f32x4 acc[TN][TM];
@@ -197,6 +208,14 @@ __global__ void __launch_bounds__((WM * WN + NLX + NLW) * 64) linear_mid_m_kerne
   if constexpr (EPI == EPI_INGEST) {
     for (int i = 0; i < nk; ++i) __builtin_amdgcn_s_barrier();
     if (p.out && nk < 0) ((float *)p.out)[threadIdx.x] = acc[0][0][0];   // never true
+    if (stamp) {
+      const uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+      if (lane == 0) {
+        uint64_t *dbg = (uint64_t *)p.bias + 2 * (blockIdx.x + blockIdx.y * gridDim.x);
+        dbg[0] = c1 - st_c0;
+        dbg[1] = r1 - st_r0;
+      }
+    }
     return;
   } else {
     // fragment read offsets inside a block (x: row & 7 == r16 & 7, tile bases are multiples of 16)
@@ -233,21 +252,72 @@ __global__ void __launch_bounds__((WM * WN + NLX + NLW) * 64) linear_mid_m_kerne
       __builtin_amdgcn_s_barrier();   // block 0 has landed
       read(0, 0, xa, wa);
     }
+    // PIPE == 2: the fragment reads of the next k-step are ISSUED between the MFMAs of the current one (one ds_read
+    // behind each MFMA) instead of in front of them: a wave issues in order, and eight 1-KiB LDS reads in a row keep
+    // the matrix pipe of its SIMD idle for ~100 cycles per k-step (round 3 ablation: the compute loop alone, no DMA,
+    // ran at ~0.6 of its MFMA time)
+    auto interleave = [&]() {
+      if constexpr (PIPE == 2) {
+        constexpr int NR = TM + TN, NM = TM * TN;
+#pragma unroll
+        for (int j = 0; j < (NR < NM ? NR : NM); ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+        }
+        if constexpr (NM > NR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+        if constexpr (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
+      }
+    };
+    if constexpr (PIPE == 2) {
+      // (the last k-block is peeled so that no branch sits between the barrier's reads and the MFMAs they hide behind)
+      for (int i = 0; i + 1 < nk; ++i) {
+        read(i, 1, xb, wb);
+        mma(xa, wa);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read(i + 1, 0, xa, wa);
+        mma(xb, wb);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (nk > 0) {
+        read(nk - 1, 1, xb, wb);
+        mma(xa, wa);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xb, wb);
+      }
+    } else
     for (int i = 0; i < nk; ++i) {
       read(i, 1, xb, wb);
       mma(xa, wa);
+      interleave();
       __builtin_amdgcn_sched_barrier(0);
       if (i + 1 < nk) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of block i are done: its slot may be refilled
         __builtin_amdgcn_s_barrier();                          // block i+1 has landed
         read(i + 1, 0, xa, wa);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PIPE != 2) __builtin_amdgcn_sched_barrier(0);
       mma(xb, wb);
+      interleave();
+      if constexpr (PIPE == 2) __builtin_amdgcn_sched_barrier(0);
     }
     }
   }
 
+  if (stamp) {
+    const uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      uint64_t *dbg = (uint64_t *)p.bias + 2 * (blockIdx.x + blockIdx.y * gridDim.x);
+      dbg[0] = c1 - st_c0;
+      dbg[1] = r1 - st_r0;
+    }
+    return;
+  }
   // ---- epilogue: lane holds rows n = g*4 + {0..3} of W (consecutive output columns) for token m = r16
   if constexpr (EPI == EPI_GATED) {
 #pragma unroll
@@ -339,6 +409,16 @@ constexpr Cfg kCfgs[] = {
     {128, 128, 4, 2, 4, 4, 4, 5, true},    // 17: tile 6 with 4 + 4 loaders
     {256, 160, 8, 1, 4, 4, 3, 3, true},    // 18: tile 7 with 4 + 4 loaders
     {256, 128, 4, 2, 4, 4, 3, 4, true},    // 19: tile 8 with 4 + 4 loaders
+    // 20..27: tiles 14 / 11 / 15 / 2 / 16 / 4 / 17 / 9 with the fragment reads of the next k-step issued BETWEEN the MFMAs
+    // of the current one (PIPE 2; round 3: -15 % on the compute loop of the 128 x 96 tile, -2..3 % on the kernel)
+    {128, 96, 4, 1, 4, 3, 4, 7, true},     // 20
+    {64, 64, 2, 2, 2, 2, 8, 9, true},      // 21
+    {64, 64, 2, 2, 4, 4, 8, 9, true},      // 22
+    {256, 48, 4, 1, 4, 2, 3, 8, false},    // 23
+    {128, 96, 4, 1, 8, 3, 4, 7, true},     // 24
+    {64, 32, 2, 2, 1, 1, 8, 12, false},    // 25
+    {128, 128, 4, 2, 4, 4, 4, 5, true},    // 26
+    {128, 48, 4, 1, 2, 1, 5, 12, false},   // 27
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -388,6 +468,14 @@ int launch_cfg(MidParams p, int cfg, int splits, hipStream_t st) {
     case 17: return launch_one<Tag, 128, 128, 4, 2, 4, 4, 4, 5, 1, EPI>(p, splits, st);
     case 18: return launch_one<Tag, 256, 160, 8, 1, 4, 4, 3, 3, 0, EPI>(p, splits, st);
     case 19: return launch_one<Tag, 256, 128, 4, 2, 4, 4, 3, 4, 1, EPI>(p, splits, st);
+    case 20: return launch_one<Tag, 128, 96, 4, 1, 4, 3, 4, 7, 2, EPI>(p, splits, st);
+    case 21: return launch_one<Tag, 64, 64, 2, 2, 2, 2, 8, 9, 2, EPI>(p, splits, st);
+    case 22: return launch_one<Tag, 64, 64, 2, 2, 4, 4, 8, 9, 2, EPI>(p, splits, st);
+    case 23: if constexpr (!G) return launch_one<Tag, 256, 48, 4, 1, 4, 2, 3, 8, 2, EPI>(p, splits, st); else break;
+    case 24: return launch_one<Tag, 128, 96, 4, 1, 8, 3, 4, 7, 2, EPI>(p, splits, st);
+    case 25: if constexpr (!G) return launch_one<Tag, 64, 32, 2, 2, 1, 1, 8, 12, 2, EPI>(p, splits, st); else break;
+    case 26: return launch_one<Tag, 128, 128, 4, 2, 4, 4, 4, 5, 2, EPI>(p, splits, st);
+    case 27: if constexpr (!G) return launch_one<Tag, 128, 48, 4, 1, 2, 1, 5, 12, 2, EPI>(p, splits, st); else break;
     default: break;
   }
   return MV_E_RANGE;
@@ -441,11 +529,12 @@ extern "C" int mv_linear_mid_m(const void *x, int64_t x_stride, const void *w_pa
   if (m == 0 || n == 0) return MV_OK;
   if (int e = check(x, x_stride, w_packed, out, out_stride, m, n, k, dtype)) return e;
   if (bias && (((uintptr_t)bias) & 7u)) return MV_E_ALIGN;
-  int flags = cfg / 100;          // bench only: +100 the DMA ring without the arithmetic (out untouched), +200 K rotation
-  cfg %= 100;
-  if (cfg < 0 || cfg >= kNumCfgs || flags > 3) return MV_E_RANGE;
+  int flags = cfg / 100;          // bench only: +100 the DMA ring without the arithmetic (out untouched), +200 K rotation,
+  cfg %= 100;                     // +400 no x DMA, +800 no W DMA (results are garbage: timing ablations)
+  if (cfg < 0 || cfg >= kNumCfgs || flags > 31) return MV_E_RANGE;   // +1600: clock stamps into `bias` (bench only)
   if (cfg == 0) cfg = auto_cfg(m, n, k, false);
-  MidParams p{x, w_packed, bias, out, x_stride, out_stride, m, n, k, 0, 0, 0, (flags & 2) ? 1 : 0};
+  MidParams p{x, w_packed, bias, out, x_stride, out_stride, m, n, k, 0, 0, 0, (flags & 2) ? 1 : 0, flags >> 2};
+  if ((flags & 16) && !bias) return MV_E_NULLPTR;
   if (flags & 1)
     return dtype == MV_BF16 ? launch_cfg<bf16_tag, EPI_INGEST>(p, cfg, 1, (hipStream_t)stream) : MV_E_DTYPE;
   return dtype == MV_BF16 ? launch_cfg<bf16_tag, EPI_PLAIN>(p, cfg, 1, (hipStream_t)stream)
@@ -461,7 +550,7 @@ extern "C" int mv_gate_up_silu_mid_m(const void *x, int64_t x_stride, const void
   if (cfg < 0 || cfg >= kNumCfgs) return MV_E_RANGE;
   if (cfg == 0) cfg = auto_cfg(m, n_inter, k, true);
   if (!kCfgs[cfg].gated_ok) return MV_E_RANGE;
-  MidParams p{x, w_gate_up_packed, nullptr, out, x_stride, out_stride, m, n_inter, k, 0, 0, 0, 0};
+  MidParams p{x, w_gate_up_packed, nullptr, out, x_stride, out_stride, m, n_inter, k, 0, 0, 0, 0, 0};
   return dtype == MV_BF16 ? launch_cfg<bf16_tag, EPI_GATED>(p, cfg, 1, (hipStream_t)stream)
                           : launch_cfg<f16_tag, EPI_GATED>(p, cfg, 1, (hipStream_t)stream);
 }
@@ -474,7 +563,7 @@ extern "C" int mv_linear_mid_m_partial(const void *x, int64_t x_stride, const vo
   if (!mv_aligned16(out_partial)) return MV_E_ALIGN;
   if (splits < 1 || splits > 16 || cfg < 0 || cfg >= kNumCfgs) return MV_E_RANGE;
   if (cfg == 0) cfg = auto_cfg(m, n * splits, k, false);
-  MidParams p{x, w_packed, nullptr, out_partial, x_stride, n, m, n, k, 0, 0, 0, 0};
+  MidParams p{x, w_packed, nullptr, out_partial, x_stride, n, m, n, k, 0, 0, 0, 0, 0};
   return dtype == MV_BF16 ? launch_cfg<bf16_tag, EPI_PARTIAL>(p, cfg, splits, (hipStream_t)stream)
                           : launch_cfg<f16_tag, EPI_PARTIAL>(p, cfg, splits, (hipStream_t)stream);
 }

@@ -55,7 +55,10 @@ MID_M_MAX = int(os.environ.get("MV_LINEAR_MID_M_MAX", "512"))   # 0 disables (ev
 MID_CFGS = {1: (128, 96, True), 2: (256, 48, False), 3: (128, 32, True), 4: (64, 32, False), 5: (256, 64, True),
             6: (128, 128, True), 7: (256, 160, True), 8: (256, 128, True), 9: (128, 48, False), 10: (64, 64, True),
             11: (64, 64, True), 12: (64, 64, True), 13: (128, 96, True), 14: (128, 96, True), 15: (64, 64, True),
-            16: (128, 96, True), 17: (128, 128, True), 18: (256, 160, True), 19: (256, 128, True)}
+            16: (128, 96, True), 17: (128, 128, True), 18: (256, 160, True), 19: (256, 128, True),
+            # 20..27: tiles 14 / 11 / 15 / 2 / 16 / 4 / 17 / 9 with their LDS reads issued between the MFMAs (round 3)
+            20: (128, 96, True), 21: (64, 64, True), 22: (64, 64, True), 23: (256, 48, False), 24: (128, 96, True),
+            25: (64, 32, False), 26: (128, 128, True), 27: (128, 48, False)}
 _TUNED_PATH = os.environ.get("MV_MID_TUNED") or os.path.join(
     os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tuned", "mid_m_gfx950.json")
 _TUNED_MS = (64, 128, 192, 256, 384, 512)

@@ -789,11 +789,16 @@ def test_linear_mid_m_every_tile(H, dtype, m, n, k, bias):
     b = _randn(n, dtype=dtype, seed=3).to(DEV) if bias else None
     exact = O.linear(x.cpu(), w.cpu(), None if b is None else b.cpu())
     wp = H.pack_weight(w)
-    for cfg in range(0, 20):
-        got = H.linear_mid_m(x, wp, n, b, cfg=cfg)
+    outs = {}
+    for cfg in range(0, 28):
+        got = outs[cfg] = H.linear_mid_m(x, wp, n, b, cfg=cfg)
         assert got.shape == (m, n) and got.dtype == dtype
         ok, worst = _ulp_ok(got.cpu(), exact, dtype, 1.0)
         assert ok, (cfg, worst)
+    # tiles 20..27 are tiles 14 / 11 / 15 / 2 / 16 / 4 / 17 / 9 with another instruction ORDER (LDS reads between the
+    # MFMAs): the same sums in the same order, bit for bit
+    for new, old in ((20, 14), (21, 11), (22, 15), (23, 2), (24, 16), (25, 4), (26, 17), (27, 9)):
+        assert torch.equal(outs[new], outs[old]), (new, old)
     # strided input rows (a column block of a wider activation)
     wide = torch.zeros(m, k + 64, dtype=dtype, device=DEV)
     wide[:, 32:32 + k] = x
@@ -807,7 +812,7 @@ def test_gate_up_silu_mid_m(H, dtype, m, inter, k):
     w = (_randn(2 * inter, k, dtype=torch.float32, seed=inter) * k ** -0.5).to(dtype).to(DEV)
     wp = H.pack_weight(w)
     want = O.gate_up_silu(x.cpu(), w.cpu(), dtype).double()
-    for cfg in (0, 1, 3, 5, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19):
+    for cfg in (0, 1, 3, 5, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 24, 26):
         got = H.gate_up_silu_mid_m(x, wp, inter, cfg=cfg)
         assert got.shape == (m, inter)
         # the fused epilogue IS the unfused pair: same GEMM (checked to 1 ulp of the exact product above), same
@@ -832,7 +837,7 @@ def test_split_k_partials_and_the_norm_behind_them(H, dtype, m, n, k, splits):
     nw = (1 + 0.1 * _randn(n, dtype=torch.float32, seed=6)).to(dtype).to(DEV)
     wp = H.pack_weight(w)
     exact = O.linear(x.cpu(), w.cpu())
-    for cfg in (0, 1, 6, 10, 11, 15, 17):
+    for cfg in (0, 1, 6, 10, 11, 15, 17, 21, 22, 26):
         part = H.linear_mid_m_partial(x, wp, n, splits, cfg=cfg)
         assert part.shape == (splits, m, n) and part.dtype == torch.float32
         assert (part.double().sum(0).cpu() - exact).abs().max() < 1e-4 * max(1.0, exact.abs().max())

@@ -23,9 +23,9 @@ SHAPES = {  # name -> (N, K, bias)
     "qwen2-72b-tp8": {"qkv": (1280, 8192, True), "o": (8192, 1024, False), "gate_up": (7392, 8192, False),
                       "lm_head": (19008, 8192, False)},
 }
-CFGS = {1: (128, 96), 2: (256, 48), 3: (128, 32), 4: (64, 32), 5: (256, 64), 6: (128, 128), 7: (256, 160),
-        8: (256, 128), 9: (128, 48), 10: (64, 64)}
-GATED_OK = (1, 3, 5, 6, 7, 8, 10)
+from minivllm_amd.layers.linear import MID_CFGS  # noqa: E402
+CFGS = {c: (bm, bn) for c, (bm, bn, _) in MID_CFGS.items()}
+GATED_OK = tuple(c for c, (_, _, g) in MID_CFGS.items() if g)
 
 
 def timed(fn, n_calls, reps=5):

@@ -1,0 +1,3 @@
+#!/bin/bash
+set -o pipefail
+python tools/dbg/mid_ablate.py > gpurun_out/r3e_ablate.log 2>&1; echo "rc=$?"; cat gpurun_out/r3e_ablate.log
