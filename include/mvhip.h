@@ -177,7 +177,10 @@ int mv_prefill_varlen(const void *q, int64_t q_stride_tok, const void *k,
  * RNG: Philox4x32-10 keyed by (seed, offset + *offset_dev, row); offset_dev
  * (device u64, may be NULL) lets a captured graph draw fresh numbers.
  * keep_mask (uint8 [B,V], may be NULL) receives the post-filter support set
- * (1 = kept), for parity tests against the reference's filtered logits. */
+ * (1 = kept), for parity tests against the reference's filtered logits.
+ * workspace (may be NULL): when ws_bytes >= 8 * batch it receives, per row, the fp32 pair {row maximum, kept
+ * mass = sum over the kept tokens of exp((logit - maximum) / temperature)} (greedy rows: {maximum, 1}) — what
+ * mv_mass_pack sends instead of the logits. */
 size_t mv_sample_workspace_bytes(int batch, int vocab);
 int mv_sample(const void *logits, int64_t ld, const float *temperatures,
               const int64_t *top_ks, const float *top_ps, const float *min_ps,
@@ -357,6 +360,20 @@ int mv_greedy_merge(const void *buf, int world, int rows, int rows_padded,
  * cand_idx int32 [rows][world*64]; mv_sample on cand_logits draws a candidate position, cand_idx maps it back.
  * The union of the per-rank candidates holds a complete top-k set, and top-p / min-p / the draw only look at that. */
 int mv_topc_width(void);
+/* f2 for rows sampled from the WHOLE vocabulary (the default SamplingParams of minivllm/sampling_params.py:41-67:
+ * top_k = -1, top_p = 1, min_p = 0) and greedy rows — an exact two-stage draw instead of the logit gather of
+ * embed_head.py:219-229.  Every rank runs mv_sample on its own shard WITH the statistics workspace (local token drawn
+ * with the row's uniform, shard maximum, shard mass); mv_mass_pack writes {maximum, mass as a binary exponent + three
+ * 8-bit mantissa pieces, three 8-bit pieces of the token's GLOBAL index} — eight exact 16-bit values — into slot [rank]
+ * of a zeroed buf [world][rows_padded][8]; after an exact sum all-reduce mv_mass_merge picks, per row, the rank r with
+ * probability mass_r * exp((max_r - max) / T) / Z from a second uniform of the same Philox counter (seed, offset +
+ * *offset_dev, row: pass the values given to mv_sample) and returns that rank's token: the softmax of the full row.
+ * Temperature 0: the rank with the largest maximum, lowest rank on ties (= argmax, lowest index). */
+int mv_mass_pack(const float *stats, const int64_t *local_tokens, int rank, int world,
+                 int64_t vocab_per_rank, int rows, int rows_padded, void *buf, int dtype, void *stream);
+int mv_mass_merge(const void *buf, const float *temperatures, uint64_t seed, uint64_t offset,
+                  const uint64_t *offset_dev, int world, int rows, int rows_padded, int64_t *tokens,
+                  int dtype, void *stream);
 int mv_topc_pack(const void *logits_local, int64_t ld, int vocab_local, int rank, int world,
                  int64_t vocab_per_rank, int rows, int rows_padded, void *buf, int dtype, void *stream);
 int mv_topc_unpack(const void *buf, int world, int rows, int rows_padded, void *cand_logits,

@@ -31,6 +31,7 @@ struct SampleParams {
   const uint64_t *offset_dev;
   int64_t *out_tokens;
   uint8_t *keep_mask;
+  float *stats;   // optional [batch][2]: {row maximum, kept mass relative to it at the row's temperature}
   int vocab;
 };
 
@@ -69,6 +70,19 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, 
     k[1] += 0xBB67AE85u;
   }
   return (float)(c[0] >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+
+// a second, independent uniform of the same (seed, offset, row) counter: word 1 of the Philox output
+__device__ __forceinline__ float philox_uniform_b(uint64_t seed, uint64_t offset, uint32_t row) {
+  uint32_t c[4] = {(uint32_t)offset, (uint32_t)(offset >> 32), row, 0u};
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k);
+    k[0] += 0x9E3779B9u;
+    k[1] += 0xBB67AE85u;
+  }
+  return (float)(c[1] >> 8) * (1.0f / 16777216.0f);  // [0, 1)
 }
 
 // ---- order-preserving keys -----------------------------------------------------
@@ -261,6 +275,10 @@ __global__ void __launch_bounds__(kThreads) sample_kernel(SampleParams p) {
     for (int i = 1; i < kWaves; ++i) win = min(win, sh.ired[i]);
     if (win == 0x7fffffff) win = 0;  // all-NaN row
     if (threadIdx.x == 0) p.out_tokens[rowi] = win;
+    if (threadIdx.x == 0 && p.stats) {
+      p.stats[2 * rowi] = xmax;
+      p.stats[2 * rowi + 1] = 1.0f;
+    }
     if (mask_row)
       for (int i = threadIdx.x; i < V; i += kThreads) mask_row[i] = (i == win);
     return;
@@ -500,6 +518,10 @@ __global__ void __launch_bounds__(kThreads) sample_kernel(SampleParams p) {
   const float before = block_exscan_f(mine, total, sh);
   const uint64_t off = p.offset + (p.offset_dev ? *p.offset_dev : 0ull);
   const float target = philox_uniform(p.seed, off, (uint32_t)rowi) * total;
+  if (threadIdx.x == 0 && p.stats) {
+    p.stats[2 * rowi] = xmax;
+    p.stats[2 * rowi + 1] = total;
+  }
 
   // owner = last thread whose prefix <= target and that holds mass
   __syncthreads();
@@ -745,7 +767,128 @@ __global__ void __launch_bounds__(64) topc_pick_kernel(const uint16_t *cand_logi
   if (lane == 0) tokens[r] = tok;
 }
 
+// f2 for rows sampled from the WHOLE vocabulary (the default SamplingParams: top_k = -1, top_p = 1, min_p = 0)
+// under tensor parallelism: an exact TWO-STAGE draw instead of the [B, V/tp] all-gather.  Every rank runs the ordinary
+// sampler on its own shard (token t_r drawn with the row's uniform u, row maximum m_r, mass S_r = sum exp((l - m_r)/T)),
+// the ranks exchange {m_r, S_r, t_r} per row — 16 bytes — through the slot scheme of the greedy path (exact 16-bit pieces
+// in slot [rank] of a zeroed buffer, summed by the all-reduce), and every rank picks the SAME rank r* with probability
+// S_r exp((m_r - M)/T) / Z from a second, independent uniform of the same Philox counter and takes t_{r*}:
+// P(token j) = P(r*) * e_j / S_{r*} = exp((l_j - M)/T) / Z, the softmax of the full row.  Greedy rows (T = 0) take the
+// rank with the largest m_r, lowest rank on ties (= the lowest token id: shards are index-ordered and a shard's argmax
+// is its lowest index).  S_r travels as {binary exponent, three 8-bit pieces of a 24-bit mantissa}: integers <= 255,
+// exact in bf16 and f16 alike.
+template <typename Tag>
+__global__ void mass_pack_kernel(const float *stats, const int64_t *local_tokens, int rank, int world,
+                                 int64_t vocab_per_rank, int rows, int rows_padded, uint16_t *buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over world * rows_padded
+  if (i >= world * rows_padded) return;
+  const int q = i / rows_padded, r = i - q * rows_padded;
+  u32x4 w = {0u, 0u, 0u, 0u};
+  if (q == rank && r < rows) {
+    const float m = stats[2 * r];
+    float mass = stats[2 * r + 1];
+    if (!(mass > 0.f) || !(mass < INFINITY)) mass = 1.0f;
+    int e;
+    const float frac = frexpf(mass, &e);                       // mass = frac * 2^e, frac in [0.5, 1)
+    const uint32_t mant = (uint32_t)(frac * 16777216.0f);       // 24 bits, exact
+    const int64_t g = local_tokens[r] + (int64_t)rank * vocab_per_rank;
+    auto f = [](float v) { return (uint32_t)elem<Tag>::st(v); };
+    w[0] = f(m) | (f((float)(e + 64)) << 16);                  // (bias 64: masses below 1 do not occur, but stay exact)
+    w[1] = f((float)(mant >> 16)) | (f((float)((mant >> 8) & 255u)) << 16);
+    w[2] = f((float)(mant & 255u)) | (f((float)((g >> 16) & 255)) << 16);
+    w[3] = f((float)((g >> 8) & 255)) | (f((float)(g & 255)) << 16);
+  }
+  *(u32x4 *)(buf + (int64_t)i * 8) = w;
+}
+
+template <typename Tag>
+__global__ void mass_merge_kernel(const uint16_t *buf, const float *temperatures, uint64_t seed, uint64_t offset,
+                                  const uint64_t *offset_dev, int world, int rows, int rows_padded, int64_t *tokens) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  auto ld = [](uint32_t half) { return elem<Tag>::ld((uint16_t)(half & 0xffffu)); };
+  const float temp = temperatures ? temperatures[r] : 1.0f;
+  float mq[16], sq[16];
+  int64_t tq[16];
+  float big = -INFINITY;
+  for (int q = 0; q < world; ++q) {
+    const u32x4 w = *(const u32x4 *)(buf + ((int64_t)q * rows_padded + r) * 8);
+    mq[q] = ld(w[0]);
+    const int e = (int)ld(w[0] >> 16) - 64;
+    const uint32_t mant = ((uint32_t)ld(w[1]) << 16) | ((uint32_t)ld(w[1] >> 16) << 8) | (uint32_t)ld(w[2]);
+    sq[q] = ldexpf((float)mant * (1.0f / 16777216.0f), e);
+    tq[q] = ((int64_t)ld(w[2] >> 16) << 16) | ((int64_t)ld(w[3]) << 8) | (int64_t)ld(w[3] >> 16);
+    if (mq[q] > big) big = mq[q];
+  }
+  int pick = 0;
+  if (temp == 0.0f) {
+    for (int q = 0; q < world; ++q)
+      if (mq[q] == big) { pick = q; break; }                  // lowest rank among the maxima (NaN rows: rank 0)
+  } else {
+    const bool degenerate = !(big > -INFINITY) || !(big < INFINITY);
+    const float inv_t = 1.4426950408889634f / fmaxf(temp, 1e-8f);
+    float z = 0.f;
+    for (int q = 0; q < world; ++q) {
+      sq[q] = degenerate ? sq[q] : sq[q] * __builtin_amdgcn_exp2f((mq[q] - big) * inv_t);
+      if (!(sq[q] >= 0.f)) sq[q] = 0.f;                        // a NaN maximum in one shard only
+      z += sq[q];
+    }
+    const uint64_t off = offset + (offset_dev ? *offset_dev : 0ull);
+    const float target = philox_uniform_b(seed, off, (uint32_t)r) * z;
+    float acc = 0.f;
+    pick = -1;
+    int last = 0;
+    for (int q = 0; q < world; ++q) {
+      if (sq[q] > 0.f) {
+        last = q;
+        acc += sq[q];
+        if (pick < 0 && target < acc) pick = q;
+      }
+    }
+    if (pick < 0) pick = last;                                 // rounding at the very end
+  }
+  tokens[r] = tq[pick];
+}
+
 }  // namespace
+
+extern "C" int mv_mass_pack(const float *stats, const int64_t *local_tokens, int rank, int world,
+                            int64_t vocab_per_rank, int rows, int rows_padded, void *buf, int dtype, void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!stats || !local_tokens || !buf) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (rows < 0 || rows_padded < rows || world < 1 || world > 16 || rank < 0 || rank >= world ||
+      vocab_per_rank * world > (1 << 24))
+    return MV_E_SHAPE;
+  if (!mv_aligned16(buf)) return MV_E_ALIGN;
+  const int n = world * rows_padded;
+  if (dtype == MV_BF16)
+    hipLaunchKernelGGL((mass_pack_kernel<bf16_tag>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats,
+                       local_tokens, rank, world, vocab_per_rank, rows, rows_padded, (uint16_t *)buf);
+  else
+    hipLaunchKernelGGL((mass_pack_kernel<f16_tag>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats,
+                       local_tokens, rank, world, vocab_per_rank, rows, rows_padded, (uint16_t *)buf);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_mass_merge(const void *buf, const float *temperatures, uint64_t seed, uint64_t offset,
+                             const uint64_t *offset_dev, int world, int rows, int rows_padded, int64_t *tokens,
+                             int dtype, void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!buf || !tokens) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (rows < 0 || rows_padded < rows || world < 1 || world > 16) return MV_E_SHAPE;
+  if (!mv_aligned16(buf)) return MV_E_ALIGN;
+  if (dtype == MV_BF16)
+    hipLaunchKernelGGL((mass_merge_kernel<bf16_tag>), dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)buf, temperatures, seed, offset, offset_dev, world, rows, rows_padded, tokens);
+  else
+    hipLaunchKernelGGL((mass_merge_kernel<f16_tag>), dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)buf, temperatures, seed, offset, offset_dev, world, rows, rows_padded, tokens);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
 
 extern "C" int mv_topc_pick(const void *cand_logits, const int32_t *cand_idx, const int64_t *pos,
                             const float *temperatures, int64_t *tokens, int rows, int width, int dtype, void *stream) {
@@ -773,11 +916,14 @@ extern "C" int mv_sample(const void *logits, int64_t ld, const float *temperatur
                          uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
                          int64_t *out_tokens, uint8_t *keep_mask, int batch, int vocab,
                          void *workspace, size_t ws_bytes, int dtype, void *stream) {
-  (void)workspace; (void)ws_bytes;
   if (batch == 0) return MV_OK;
   if (!logits || !out_tokens) return MV_E_NULLPTR;
   if (batch < 0 || vocab <= 0 || ld < vocab) return MV_E_SHAPE;
+  if (workspace && (((uintptr_t)workspace) & 3u)) return MV_E_ALIGN;
   SampleParams p;
+  // a workspace of >= 8 bytes per row receives {row maximum, kept mass} (fp32 pairs): what the tensor-parallel
+  // two-stage draw (mv_mass_pack / mv_mass_merge) exchanges instead of the logits
+  p.stats = (workspace && ws_bytes >= (size_t)batch * 8) ? (float *)workspace : nullptr;
   p.logits = logits; p.ld = ld; p.temperatures = temperatures; p.top_ks = top_ks;
   p.top_ps = top_ps; p.min_ps = min_ps; p.seed = seed; p.offset = offset;
   p.offset_dev = offset_dev; p.out_tokens = out_tokens; p.keep_mask = keep_mask; p.vocab = vocab;

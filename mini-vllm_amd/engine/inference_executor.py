@@ -22,7 +22,7 @@ import torch
 from ..config import Config
 from ..layers.sampler import Sampler
 from ..parallel_state import (decode_step_is_native, get_custom_all_reduce as get_custom_allreduce,
-                              get_tensor_parallel_world_size, tp_candidate_tokens, tp_greedy_tokens)
+                              get_tensor_parallel_world_size, tp_candidate_tokens, tp_greedy_tokens, tp_mass_tokens)
 from ..utils.context import reset_context, set_context
 from .. import hip_ops
 from .input_builder import BatchInputs, InputBuilder
@@ -70,6 +70,8 @@ class InferenceExecutor:
         self.graphs: dict[int, torch.cuda.CUDAGraph] = {}
         self.greedy_graphs: dict[int, torch.cuda.CUDAGraph] = {}   # TP > 1: per-rank argmax instead of the logit gather
         self.cand_graphs: dict[int, torch.cuda.CUDAGraph] = {}     # TP > 1: per-rank top-64 candidates (sampled rows with 1 <= top_k <= 64)
+        self.mass_graphs: dict[int, torch.cuda.CUDAGraph] = {}     # TP > 1: two-stage draw (rows sampled from the whole vocabulary)
+        self._mass_capture = "no"
         self._cand_capture = "no"                                  # "no" | "lazy" | "done"
         self.graph_bs: list[int] = []
         self.graph_vars: dict[str, torch.Tensor] = {}
@@ -313,8 +315,10 @@ class InferenceExecutor:
 
     def _tp_mode(self, sequences) -> str:
         """How a tensor-parallel batch gets its tokens: 'greedy' (per-rank argmax merge), 'cand' (per-rank top-64
-        candidates: every row greedy or with 1 <= top_k <= 64, 16-bit logits) or 'gather' (all-gather of the
-        [B, V/tp] logits: everything else).  TP = 1: 'gather' (the plain sampler on the full row)."""
+        candidates: every row greedy or with 1 <= top_k <= 64, 16-bit logits), 'mass' (two-stage draw: every row
+        greedy or sampled from the whole vocabulary — top_k off, top_p = 1, min_p = 0, the default SamplingParams) or
+        'gather' (all-gather of the [B, V/tp] logits: everything else, i.e. nucleus / min-p / large top-k rows).
+        TP = 1: 'gather' (the plain sampler on the full row)."""
         if self.tp_size == 1 or self.sampler is None:
             return "gather"
         if all(s.temperature == 0 for s in sequences):
@@ -322,12 +326,25 @@ class InferenceExecutor:
         if self.dtype in (torch.bfloat16, torch.float16) and self.config.hf_config.vocab_size <= 1 << 24 and all(
                 s.temperature == 0 or 0 < s.top_k <= hip_ops.TOPC for s in sequences):
             return "cand"
+        vocab = self.config.hf_config.vocab_size
+        if self.dtype in (torch.bfloat16, torch.float16) and vocab <= 1 << 24 and self.tp_size <= 16 and all(
+                s.temperature == 0 or ((s.top_k <= 0 or s.top_k >= vocab) and s.top_p >= 1.0 and s.min_p <= 0.0)
+                for s in sequences):
+            return "mass"       # the default SamplingParams: the whole vocabulary, an exact two-stage draw
         return "gather"
 
     def _cand_tokens(self, logits_local, t, k, p, m):
         """'cand' mode, eager: the sampler (one Philox step, like any other batch) on the gathered candidates."""
         return tp_candidate_tokens(logits_local, lambda cl: self.sampler(cl, temperatures=t, top_ks=k, top_ps=p, min_ps=m),
                                    temperatures=t.float().contiguous())
+
+    def _mass_tokens(self, logits_local, t, k, p, m):
+        """'mass' mode, eager: the sampler on this rank's shard (one Philox step), then the 16-byte-per-row exchange."""
+        def local(ll):
+            return self.sampler(ll, temperatures=t, top_ks=k, top_ps=p, min_ps=m, return_stats=True)
+        toks = tp_mass_tokens(logits_local, local, t.float().contiguous(), self.sampler.seed, self.sampler.calls + 1,
+                              self.sampler.offset_dev)
+        return toks
 
     def _greedy_merge(self, logits_local, t, k, p, m):
         """Tokens of an all-greedy batch from this rank's vocab shard (temperature 0 rows: the sampler
@@ -350,6 +367,8 @@ class InferenceExecutor:
             return self._greedy_merge(logits, t, k, p, m).tolist()
         if mode == "cand":
             return self._cand_tokens(logits, t, k, p, m).tolist()
+        if mode == "mass":
+            return self._mass_tokens(logits, t, k, p, m).tolist()
         return self.sampler(logits, temperatures=t, top_ks=k, top_ps=p, min_ps=m).tolist()
 
     def _update_metrics(self, sequences, prefill: bool) -> None:
@@ -380,6 +399,8 @@ class InferenceExecutor:
                 self._capture_cand()
             if self.cand_graphs:
                 return "cand", self.cand_graphs
+        if mode == "mass" and self.mass_graphs:
+            return "mass", self.mass_graphs
         if capture and self._general_capture == "lazy":
             self._drop_speculation()
             torch.cuda.synchronize(self.device)
@@ -435,6 +456,7 @@ class InferenceExecutor:
                     # here, out of the same pool, before any sequence is live (a capture in mid-serving would stall
                     # every rank for seconds and take its memory from whatever the KV pool left over)
                     self._capture_cand()
+                    self._capture_mass()
                 if general_ok and self.greedy_graphs and decode_step_is_native(self.dtype, hf.hidden_size, hf.vocab_size):
                     # the gathered-logits family needs RCCL nodes in its graphs: captured on the first batch with
                     # a sampled row (_graph_bucket), so that a greedy-only workload never captures a collective
@@ -448,8 +470,9 @@ class InferenceExecutor:
             self.graphs.clear()
             self.greedy_graphs.clear()
             self.cand_graphs.clear()
+            self.mass_graphs.clear()
             self.graph_pool = None
-            self._general_capture = self._cand_capture = "no"
+            self._general_capture = self._cand_capture = self._mass_capture = "no"
             self._recover_from_failed_capture()
 
     def _capture_general(self) -> None:
@@ -495,6 +518,19 @@ class InferenceExecutor:
             self._cand_capture = "no"
             self._recover_from_failed_capture()
 
+    def _capture_mass(self) -> None:
+        """The two-stage-draw graphs (batches of greedy rows / rows sampled from the whole vocabulary under TP)."""
+        self._neutralise_graph_inputs()
+        try:
+            for bs in reversed(self.graph_bs):
+                self._capture_one(bs, mode="mass")
+            self._mass_capture = "done"
+        except Exception as e:
+            logger.warning("Failed to capture the two-stage-draw graphs (such batches gather their logits): %s", e)
+            self.mass_graphs.clear()
+            self._mass_capture = "no"
+            self._recover_from_failed_capture()
+
     def _recover_from_failed_capture(self) -> None:
         reset_context()
         # a failed capture leaves torch's side capture stream current (torch.cuda.graph.__exit__
@@ -525,6 +561,12 @@ class InferenceExecutor:
             toks = tp_candidate_tokens(out, lambda cl: hip_ops.sample(
                 cl, d[0, :bs], self._dev_samp_i64[:bs], d[1, :bs], d[2, :bs], seed=self.sampler.seed, offset=0,
                 offset_dev=gv["rng_offset"]), temperatures=d[0, :bs])
+        elif mode == "mass":  # TP > 1, rows greedy or sampled from the whole vocabulary: two-stage draw, no logit gather
+            out = gv["logits_local"][:bs]
+            out.copy_(self.model.compute_logits(hidden, gather=False))
+            toks = tp_mass_tokens(out, lambda ll: hip_ops.sample(
+                ll, d[0, :bs], self._dev_samp_i64[:bs], d[1, :bs], d[2, :bs], seed=self.sampler.seed, offset=0,
+                offset_dev=gv["rng_offset"], return_stats=True), d[0, :bs], self.sampler.seed, 0, gv["rng_offset"])
         else:
             out = gv["logits"][:bs]
             out.copy_(self.model.compute_logits(hidden))
@@ -548,7 +590,7 @@ class InferenceExecutor:
             self._graph_forward(bs, mode=mode)
         if self.graph_pool is None:
             self.graph_pool = graph.pool()
-        {"greedy": self.greedy_graphs, "cand": self.cand_graphs, "gather": self.graphs}[mode][bs] = graph
+        {"greedy": self.greedy_graphs, "cand": self.cand_graphs, "mass": self.mass_graphs, "gather": self.graphs}[mode][bs] = graph
         torch.cuda.synchronize(self.device)
         reset_context()
 
@@ -636,6 +678,7 @@ class InferenceExecutor:
         self.graphs.clear()
         self.greedy_graphs.clear()
         self.cand_graphs.clear()
+        self.mass_graphs.clear()
         self.graph_vars.clear()
         self.graph_pool = None
         self.kv_cache = None

@@ -92,6 +92,9 @@ _SIGNATURES = {
     "mv_greedy_pack": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int,
                                c_void_p]),
     "mv_greedy_merge": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mv_mass_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mv_mass_merge": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                              c_void_p]),
     "mv_topc_width": (c_int, []),
     "mv_topc_pack": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mv_topc_unpack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
@@ -424,14 +427,16 @@ def prefill_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen
 
 # ---------------------------------------------------------------- K8
 def sample(logits, temperatures, top_ks, top_ps, min_ps, seed: int = 0, offset: int = 0,
-           offset_dev=None, return_mask: bool = False):
-    """logits [B,V]; per-row params [B].  Returns int64 tokens [B] (and the uint8 keep mask)."""
+           offset_dev=None, return_mask: bool = False, return_stats: bool = False):
+    """logits [B,V]; per-row params [B].  Returns int64 tokens [B] (and the uint8 keep mask; and, with
+    ``return_stats``, fp32 [B, 2] = {row maximum, kept mass}: the input of ``mass_pack``)."""
     _need_cuda(logits, temperatures, top_ks, top_ps, min_ps)
     b, v = logits.shape
     if logits.stride(-1) != 1:
         logits = logits.contiguous()
     out = torch.empty((b,), dtype=torch.int64, device=logits.device)
     mask = torch.empty((b, v), dtype=torch.uint8, device=logits.device) if return_mask else None
+    stats = torch.empty((b, 2), dtype=torch.float32, device=logits.device) if return_stats else None
 
     def f32(x):
         return None if x is None else (x if x.dtype == torch.float32 else x.float())
@@ -439,8 +444,10 @@ def sample(logits, temperatures, top_ks, top_ps, min_ps, seed: int = 0, offset: 
     temperatures, top_ps, min_ps = f32(temperatures), f32(top_ps), f32(min_ps)
     _check(_lib.mv_sample(logits.data_ptr(), logits.stride(0), _ptr(temperatures), _ptr(tk), _ptr(top_ps),
                           _ptr(min_ps), int(seed) & (2**64 - 1), int(offset) & (2**64 - 1),
-                          _ptr(offset_dev), out.data_ptr(), _ptr(mask), b, v, None, 0, _dt(logits),
-                          _stream()), "mv_sample")
+                          _ptr(offset_dev), out.data_ptr(), _ptr(mask), b, v, _ptr(stats), 8 * b if return_stats else 0,
+                          _dt(logits), _stream()), "mv_sample")
+    if return_stats:
+        return (out, mask, stats) if return_mask else (out, stats)
     return (out, mask) if return_mask else out
 
 
@@ -671,6 +678,30 @@ def topc_unpack(buf, rows: int):
     _check(_lib.mv_topc_unpack(buf.data_ptr(), world, rows, rows_padded, cl.data_ptr(), ci.data_ptr(), _dt(buf), _stream()),
            "mv_topc_unpack")
     return cl, ci
+
+
+def mass_pack(stats, local_tokens, rank: int, world: int, vocab_per_rank: int, rows_padded: int, dtype):
+    """-> buf [world, rows_padded, 8] in the logits' 16-bit dtype (see mv_mass_pack)."""
+    _need_cuda(stats, local_tokens)
+    rows = local_tokens.shape[0]
+    assert stats.dtype == torch.float32 and stats.shape == (rows, 2) and stats.is_contiguous()
+    assert local_tokens.dtype == torch.int64 and dtype in (torch.bfloat16, torch.float16)
+    buf = torch.empty((world, rows_padded, 8), dtype=dtype, device=stats.device)
+    _check(_lib.mv_mass_pack(stats.data_ptr(), local_tokens.data_ptr(), rank, world, vocab_per_rank, rows, rows_padded,
+                             buf.data_ptr(), _DTYPES[dtype], _stream()), "mv_mass_pack")
+    return buf
+
+
+def mass_merge(buf, rows: int, temperatures, seed: int = 0, offset: int = 0, offset_dev=None):
+    """Summed ``mass_pack`` buffers -> int64 tokens [rows] (see mv_mass_merge; seed / offset as given to ``sample``)."""
+    _need_cuda(buf, temperatures)
+    world, rows_padded, _ = buf.shape
+    assert temperatures is None or (temperatures.dtype == torch.float32 and temperatures.is_contiguous())
+    out = torch.empty((rows,), dtype=torch.int64, device=buf.device)
+    _check(_lib.mv_mass_merge(buf.data_ptr(), _ptr(temperatures), int(seed) & (2**64 - 1), int(offset) & (2**64 - 1),
+                              _ptr(offset_dev), world, rows, rows_padded, out.data_ptr(), _dt(buf), _stream()),
+           "mv_mass_merge")
+    return out
 
 
 def topc_pick(cand_logits, cand_idx, pos, temperatures=None):

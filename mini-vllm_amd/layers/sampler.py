@@ -36,4 +36,4 @@ class Sampler(nn.Module):
             min_ps = torch.zeros(b, device=dev)
         self.calls += 1
         return hip_ops.sample(logits, temperatures, top_ks, top_ps, min_ps, seed=self.seed,
-                              offset=self.calls, offset_dev=self.offset_dev)
+                              offset=self.calls, offset_dev=self.offset_dev, return_stats=bool(unused.get("return_stats")))

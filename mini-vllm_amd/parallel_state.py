@@ -146,6 +146,24 @@ def tp_candidate_tokens(logits_local: torch.Tensor, sample_fn, temperatures: tor
     return hip_ops.topc_pick(cand_logits, cand_idx, pos, temperatures)
 
 
+def tp_mass_tokens(logits_local: torch.Tensor, sample_stats_fn, temperatures: torch.Tensor, seed: int, offset: int,
+                   offset_dev=None) -> torch.Tensor:
+    """Tokens of rows sampled from the WHOLE vocabulary (top_k off, top_p = 1, min_p = 0: the default SamplingParams)
+    or greedy, without the logit gather: an exact two-stage draw.  ``sample_stats_fn(logits_local) ->
+    (local tokens, fp32 [B, 2] {shard maximum, shard mass})`` is the ordinary sampler on this rank's shard; the ranks
+    exchange 16 bytes per row through the slot scheme (peer-to-peer all-reduce when it is up: no backend collective)
+    and pick the same rank with probability proportional to its mass from a second uniform of the same Philox counter
+    (``seed`` / ``offset`` / ``offset_dev`` = what the sampler call used), then take that rank's token
+    (mv_mass_pack / mv_mass_merge): the softmax of the full row."""
+    from . import hip_ops
+
+    n, vpr = logits_local.shape
+    local, stats = sample_stats_fn(logits_local)
+    buf = hip_ops.mass_pack(stats, local, _state["rank"], _state["size"], vpr, n, logits_local.dtype)
+    tp_all_reduce(buf.view(-1))
+    return hip_ops.mass_merge(buf, n, temperatures, seed, offset, offset_dev)
+
+
 def decode_step_is_native(dtype: torch.dtype, hidden_size: int, vocab_size: int) -> bool:
     """True when an all-greedy decode step of a model with these dimensions needs no backend collective: every
     all-reduce and the greedy exchange run on this library's peer-to-peer kernel (-> the step captures into a

@@ -597,6 +597,69 @@ def test_topc_greedy_rows_break_ties_towards_the_lowest_token_id(H, dtype):
     assert merged.tolist()[:4] == want[:4]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("world", [2, 8])
+def test_mass_two_stage_draw_is_the_full_row_softmax(H, dtype, world):
+    """f2 for the default SamplingParams (the whole vocabulary): every rank samples its own shard and reports {shard
+    maximum, shard mass, local token}; the merge picks a rank by mass from an independent uniform.  Checked here with
+    the ranks emulated on one device (the slots are summed on the host: x + 0, what the all-reduce does):
+      * the pack / merge round trip is exact (maximum, mass to 2^-24 relative, token index),
+      * greedy rows name the full row's argmax, lowest index on ties (also across shards),
+      * chi-square of 24 000 draws against the softmax of the full row, for two temperatures,
+      * a shard whose logits are all -inf is never picked."""
+    vocab, B = 64 * world, 4
+    vpr = vocab // world
+    g = torch.Generator().manual_seed(100 + world)
+    full = (torch.randn(B, vocab, generator=g) * 2).to(dtype)
+    full[2, 5] = full[2, vpr + 3] = float(full[2].float().max()) + 1.0       # greedy row: a tie across two shards
+    full[3, vpr:2 * vpr] = float("-inf")                                       # a dead shard in a sampled row
+    full = full.to(DEV)
+    temps = torch.tensor([1.0, 0.6, 0.0, 1.3], device=DEV)
+    ks = torch.full((B,), -1, dtype=torch.int64, device=DEV)
+    ones, zeros = torch.ones(B, device=DEV), torch.zeros(B, device=DEV)
+
+    def draw(offset):
+        bufs = []
+        for r in range(world):
+            shard = full[:, r * vpr:(r + 1) * vpr].contiguous()
+            local, stats = H.sample(shard, temps, ks, ones, zeros, seed=9, offset=offset, return_stats=True)
+            bufs.append((H.mass_pack(stats, local, r, world, vpr, B, dtype), stats, local))
+        summed = torch.stack([b.float() for b, _, _ in bufs]).sum(0).to(dtype)
+        return H.mass_merge(summed, B, temps, seed=9, offset=offset), bufs, summed
+
+    toks, bufs, summed = draw(1)
+    # round trip of the statistics through the exact 16-bit pieces
+    for r, (buf, stats, local) in enumerate(bufs):
+        mine = summed[r].float()
+        assert torch.equal(mine[:, 0], stats[:, 0].to(dtype).float())
+        mant = mine[:, 2] * 65536 + mine[:, 3] * 256 + mine[:, 4]
+        mass = torch.ldexp(mant / 2 ** 24, (mine[:, 1] - 64).int())
+        torch.testing.assert_close(mass, stats[:, 1], rtol=2 ** -23, atol=0)
+        gidx = (mine[:, 5] * 65536 + mine[:, 6] * 256 + mine[:, 7]).long()
+        assert torch.equal(gidx, local + r * vpr)
+        want_mass = ((shard_f := full[:, r * vpr:(r + 1) * vpr].float()) - stats[:, :1]).div(temps.clamp_min(1e-8)[:, None]).exp().sum(1)
+        ok = temps > 0
+        ok[3] = ok[3] and r != 1
+        torch.testing.assert_close(stats[ok, 1], want_mass[ok], rtol=2e-3, atol=0)
+    assert toks[2].item() == 5                                                  # greedy, tie: the lowest token id
+    n_draws = 24000
+    counts = torch.zeros(B, vocab, dtype=torch.float64)
+    for off in range(n_draws // 8):                                             # 8 sampled rows' worth per call? no: per row
+        t = draw(off + 2)[0].cpu()
+        counts[torch.arange(B), t] += 1
+    n = counts.sum(1)
+    for b in (0, 1, 3):
+        p = torch.softmax(full[b].double().cpu() / float(temps[b]), dim=-1)
+        assert counts[b][p == 0].sum() == 0                                     # (the dead shard of row 3)
+        keep = p * n[b] >= 5                                                    # chi-square on cells with enough mass
+        exp = torch.cat([p[keep] * n[b], (p[~keep].sum() * n[b]).view(1)])
+        obs = torch.cat([counts[b][keep], counts[b][~keep].sum().view(1)])
+        chi2 = (((obs - exp) ** 2) / exp.clamp_min(1e-9)).sum().item()
+        dof = int(keep.sum())
+        assert chi2 < dof + 5 * (2 * dof) ** 0.5, (b, chi2, dof)
+    assert (counts[2] > 0).sum() == 1                                           # the greedy row never moves
+
+
 # ------------------------------------------------------------------ K10
 def _ulp_ok(got, exact, dtype, ulps):
     """|got - exact| <= ulps units in the last place of ``dtype`` at the magnitude of ``exact``

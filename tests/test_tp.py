@@ -469,7 +469,7 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
             real_mode = ex._tp_mode
             ex._tp_mode = lambda seqs: (modes.add(real_mode(seqs)), real_mode(seqs))[1]
             out = [o_["token_ids"] for o_ in llm.generate(prompts, sp, use_tqdm=False)]
-            run.last = dict(modes=modes, cand_graphs=bool(ex.cand_graphs))
+            run.last = dict(modes=modes, cand_graphs=bool(ex.cand_graphs), mass_graphs=bool(ex.mass_graphs))
             return out, bool(ex.greedy_graphs), ex.spec_hits, parallel_state.get_custom_all_reduce() is not None
         finally:
             llm.exit()
@@ -515,3 +515,18 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
     assert [len(t) for t in c_graph] == [12] * len(prompts)
     if p2p:
         assert run.last["cand_graphs"] and c_graph == c_eager
+    # rows with the DEFAULT SamplingParams (temperature 1, top_k = -1, top_p = 1: the whole vocabulary), 16-bit logits: no
+    # logit gather either — an exact two-stage draw (every rank samples its shard, 16 bytes per row are exchanged, the
+    # ranks pick the same rank by shard mass; mv_mass_pack / mv_mass_merge).  Same checks: the mode ran, both ranks drew
+    # the same tokens (or the run would hang / mismatch), eager and captured replay agree; the distribution itself is
+    # checked against the full-row softmax by tests/test_gpu_ops.py
+    default = SamplingParams(max_tokens=12, ignore_eos=True)
+    assert (default.temperature, default.top_k, default.top_p, default.min_p) == (1.0, -1, 1.0, 0.0)
+    mixed = [default, SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True), SamplingParams(temperature=0.7, max_tokens=12, ignore_eos=True)]
+    m_eager = run(2, "bfloat16", sp=mixed, max_num_seqs=len(prompts))[0]
+    assert run.last["modes"] == {"mass"} and [len(t) for t in m_eager] == [12] * len(prompts)
+    assert all(0 <= t < 320 for row in m_eager for t in row)
+    assert m_eager[1] == a[1]                                   # the greedy row of the mixed batch: the all-greedy run's tokens
+    m_graph, _, _, p2p = run(2, "bfloat16", eager=False, sp=mixed, max_num_seqs=len(prompts))
+    if p2p:
+        assert run.last["mass_graphs"] and run.last["modes"] == {"mass"} and m_graph == m_eager
