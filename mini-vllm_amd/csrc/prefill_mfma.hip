@@ -12,6 +12,8 @@
 //   O^T[d][q] += V^T P^T     the S^T accumulator is reused in place as the B operand (its key index
 //                            is the register index), A = V^T via ds_read_b64_tr_b16 transposed reads
 // so P never goes through LDS and the rescale factor of a query row is a per-lane scalar.
+#include <type_traits>
+
 #include "prefill.h"
 
 namespace {
@@ -55,6 +57,44 @@ __device__ __forceinline__ int v_off(int row, int ch) {
   return row * ROW_BYTES + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
 }
 
+// ---- round 3: hand-placed LDS reads --------------------------------------------------------------------------
+// What hipcc makes of the plain form of this loop (ROCm 7.2, -save-temps): every pair of QK^T MFMAs sits behind its own
+// `ds_read_b128 x2; s_waitcnt lgkmcnt(0)` (eight fully exposed LDS round trips per tile), and the first transposed V
+// read is preceded by a compiler-inserted `s_waitcnt vmcnt(0)`: the backend cannot tell that the LDS-DMA of tile t+1
+// (in flight since the top of the iteration) writes the OTHER buffer, so the whole DMA latency lands in front of PV.
+// With PIPE the K / V fragment reads are inline assembly (invisible to that analysis), issued two k-steps (K) and one
+// 16-key group (V; the first group before the softmax) ahead of the MFMAs that consume them, and retired by counted
+// `s_waitcnt lgkmcnt(N)` statements that name the fragment registers as read-write operands, so no MFMA can be
+// scheduled above the wait that covers its operands (cdna_hip_programming.md §5.7 form (ii)).  LDS operations complete
+// in order, so a count of "my newer reads" stays safe when the compiler issues LDS operations of its own in between;
+// scalar loads (which share the counter and return out of order) must not be in flight: the block-table entry of the
+// paged form is therefore fetched with a vector load.
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+template <int OFF>
+__device__ __forceinline__ void ds_r128(u32x4 &d, uint32_t a) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "i"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void ds_r64tr(u32x2 &d, uint32_t a) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(a), "i"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait2(u32x4 &a, u32x4 &b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait1(u32x2 &a, u32x2 &b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait8(u32x2 (&lo)[4], u32x2 (&hi)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
+               : "n"(N));
+}
+
 // Round 2 (profiles/r02_prefill_kernel.md): the softmax arithmetic is scalar f32 (v_fma_f32 / v_exp_f32 / v_add_f32;
 // the packed v_pk_* forms cost more issue cycles beside MFMAs than the two ops they replace, and this file is built
 // with -fno-slp-vectorize so that the compiler does not pair them either), and a full tile's DMA source addresses
@@ -62,15 +102,14 @@ __device__ __forceinline__ int v_off(int row, int ch) {
 // 743 -> 850 TFLOP/s on 4 x 4096 tokens, 28/4 heads.
 // NW = waves per workgroup (32 query rows each): 4 (two workgroups per CU) or 8 (one; the K/V tile and its DMA
 // instructions — ~100 issue cycles apiece — are shared by twice the rows)
-template <typename Tag, int NW>
-__global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams p) {
+template <typename Tag, int NW, bool PIPE>
+__global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams p, float rescale_thr) {
+  constexpr int NBUF = 2;   // K|V tile buffers in LDS
   constexpr int BM = NW * 32;   // query rows per workgroup
   constexpr int PP = 16 / NW;   // 1-KiB DMA pieces (4 rows) of a K tile per wave, and as many of the V tile
   typedef typename elem<Tag>::T T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // two K|V tile buffers: tile t+1 is written while tile t is being read -> ONE barrier per tile
-  char *ldsK = smem;
-  char *ldsV = smem + TILE_BYTES;
 
   const int tid = threadIdx.x;
   // the wave index as a SCALAR: everything derived from it (the diagonal test below) then branches on
@@ -139,6 +178,13 @@ __global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams 
     vrel[i] = (int64_t)row * vstride + (pc ^ (((row & 3) << 2) | ((row >> 2) & 3))) * 8;
   }
   bool tile_ok_next = true;
+  // (PIPE: through the vector memory path — mbcnt is 0 in every lane but opaque to the compiler — so that no scalar
+  // load is outstanding beside the hand-counted LDS waits)
+  auto table_entry = [&](int bi) -> int {
+    const int32_t *e = p.block_tables + (int64_t)seq * p.table_stride + bi;
+    if constexpr (PIPE) return __builtin_amdgcn_readfirstlane(e[__builtin_amdgcn_mbcnt_lo(0u, 0u)]);
+    else return *e;
+  };
   auto dma = [&](int t, int buf) {
     {
       const int kv0f = t * BN;
@@ -147,7 +193,7 @@ __global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams 
         tile_ok_next = true;
         if (paged) {
           const int bi = kv0f / p.block_size;
-          const int blk = p.block_tables[(int64_t)seq * p.table_stride + bi];
+          const int blk = table_entry(bi);
           tile_ok_next = blk >= 0 && blk < p.num_blocks;
           base_row = (int64_t)(tile_ok_next ? blk : 0) * p.block_size + (kv0f - bi * p.block_size);
         }
@@ -169,7 +215,7 @@ __global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams 
     tile_ok_next = true;
     if (paged) {
       const int bi = kv0 / p.block_size;
-      const int blk = p.block_tables[(int64_t)seq * p.table_stride + bi];
+      const int blk = table_entry(bi);
       tile_ok_next = blk >= 0 && blk < p.num_blocks;  // a hole: read block 0, mask the whole tile
       base_row = (int64_t)(tile_ok_next ? blk : 0) * p.block_size + (kv0 - bi * p.block_size);
     }
@@ -214,29 +260,68 @@ __global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler does not count LDS-DMA completions)
   }
   __syncthreads();
-  for (int t = 0; t < n_tiles; ++t) {
-    ldsK = smem + (t & 1) * 2 * TILE_BYTES;
-    ldsV = ldsK + TILE_BYTES;
-    const bool have_next = t + 1 < n_tiles;
-    if (have_next) dma(t + 1, (t + 1) & 1);  // global -> the other LDS buffer, in flight during this tile's MFMAs
-    const int kv0 = t * BN;
-
+  // (PIPE: the per-lane LDS read addresses once, relative to buffer 0; the loop below is unrolled over the two buffers
+  // so that the buffer, the 32-key half and the 16-key group are instruction immediates: no address arithmetic per tile)
+  uint32_t ka0[NS], va_lo[NDT], va_hi[NDT];
+  if constexpr (PIPE) {
+    const uint32_t base = lds_addr(smem);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) ka0[s] = base + koff[s];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      va_lo[dt] = base + TILE_BYTES + voff_lo[dt];
+      va_hi[dt] = base + TILE_BYTES + voff_hi[dt];
+    }
+  }
+  // ---- the three phases of a tile.  BO = byte offset of the tile's K|V buffer (compile time: the loop is unrolled
+  //      over the two buffers), add = a run-time addend of the read addresses (0 in the shipped loop)
+  f32x16 sacc[2];
+  u32x2 vlo[1][NDT], vhi[1][NDT];     // PIPE: the V^T fragments of one 16-key group (re-filled behind each MFMA)
+  u32x4 pf[2][2];                     // P^T fragments of the tile
+  auto qk_phase = [&](auto BOc, const uint32_t add) __attribute__((always_inline)) {
+    constexpr int BO = decltype(BOc)::value;
     // ---- S^T = K Q^T : two 32-key tiles (raw, unscaled scores; first k-step starts from an inline 0)
-    f32x16 sacc[2];
-    {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (PIPE) {
+      u32x4 kf[2][2];                   // two sets of K fragments: reads run one k-step (two MFMAs) ahead
+      uint32_t ka[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) ka[s] = ka0[s] + add;
+      ds_r128<BO>(kf[0][0], ka[0]);
+      ds_r128<BO + 32 * ROW_BYTES>(kf[0][1], ka[0]);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) {
+          ds_r128<BO>(kf[(s + 1) & 1][0], ka[s + 1]);
+          ds_r128<BO + 32 * ROW_BYTES>(kf[(s + 1) & 1][1], ka[s + 1]);
+          lgkm_wait2<2>(kf[s & 1][0], kf[s & 1][1]);
+        } else {
+          // the first group of V^T fragments goes out before the last wait: it lands under the softmax
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) {
+            ds_r64tr<BO>(vlo[0][dt], va_lo[dt] + add);
+            ds_r64tr<BO>(vhi[0][dt], va_hi[dt] + add);
+          }
+          lgkm_wait2<2 * NDT>(kf[s & 1][0], kf[s & 1][1]);
+        }
+        sacc[0] = mfma<Tag>(kf[s & 1][0], qf[s], s == 0 ? zero16 : sacc[0]);
+        sacc[1] = mfma<Tag>(kf[s & 1][1], qf[s], s == 0 ? zero16 : sacc[1]);
+      }
+    } else {
       // the two 32-key accumulators alternate: a dependent MFMA issued right behind its predecessor waits
       // for the whole 16-pass latency, an independent one issues as soon as the pipe is free
-      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const char *k1 = ldsK + 32 * ROW_BYTES;  // (row + 32) & 15 == row & 15: same swizzle
-      sacc[0] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(ldsK + koff[0]), qf[0], zero16);
+      const char *k0_ = smem + BO, *k1 = k0_ + 32 * ROW_BYTES;  // (row + 32) & 15 == row & 15: same swizzle
+      sacc[0] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(k0_ + koff[0]), qf[0], zero16);
       sacc[1] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(k1 + koff[0]), qf[0], zero16);
 #pragma unroll
       for (int s = 1; s < NS; ++s) {
-        sacc[0] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(ldsK + koff[s]), qf[s], sacc[0]);
+        sacc[0] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(k0_ + koff[s]), qf[s], sacc[0]);
         sacc[1] = mfma<Tag>(*reinterpret_cast<const u32x4 *>(k1 + koff[s]), qf[s], sacc[1]);
       }
     }
-
+  };
+  auto softmax_phase = [&](const int t) __attribute__((always_inline)) {
+    const int kv0 = t * BN;
     // ---- mask (only tiles that touch the diagonal / the ragged end: wave-uniform branch)
     if ((kv0 + BN - 1 > wave_qpos_min) || (kv0 + BN > sk) || !tile_ok) {
       const int klim = tile_ok ? min(qidx + shift, sk - 1) : -1;  // last key this query row may see
@@ -256,7 +341,10 @@ __global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams 
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kt][i]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx * scale_log2);  // scale > 0: max commutes with the scaling
-    if (!__all(m_new == m_run)) {  // some row's maximum moved: rescale (skipped on most tiles)
+    // rescale_thr = 0: rescale whenever some row's maximum moved.  > 0 (log2 units): only when one moved by more than
+    // that — the stale maximum then leaves probabilities of up to 2^thr in P (fp32 sums, 16-bit P with the same
+    // relative rounding), and the 64 multiplies of the O rescale leave most tiles (cdna_hip_programming.md T13)
+    if (!__all(m_new - m_run <= rescale_thr)) {
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
       l_run *= alpha;
@@ -280,9 +368,7 @@ __global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams 
         }
       l_run += (rs[0] + rs[1]) + (rs[2] + rs[3]);
     }
-
     // ---- P^T as MFMA B operand: registers 8*s2 .. 8*s2+7 of a 32-key tile are k-step s2
-    u32x4 pf[2][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -290,32 +376,90 @@ __global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams 
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           pf[kt][s2][j] = pack2<Tag>(sacc[kt][8 * s2 + 2 * j], sacc[kt][8 * s2 + 2 * j + 1]);
-
-    // ---- O^T += V^T P^T   (rows 32kt + 16s2 + ... keep (row & 3) and ((row >> 2) & 3) of the base row:
-    //      the swizzle term is loop invariant, only the row base moves by a multiple of 16 rows)
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const char *vb_ = ldsV + (kt * 32 + 16 * s2) * ROW_BYTES;
-        u32x4 a[NDT];
+  };
+  // ---- O^T += V^T P^T   (rows 32kt + 16s2 + ... keep (row & 3) and ((row >> 2) & 3) of the base row:
+  //      the swizzle term is loop invariant, only the row base moves by a multiple of 16 rows)
+  auto pv_phase = [&](auto BOc, const uint32_t add) __attribute__((always_inline)) {
+    constexpr int BO = decltype(BOc)::value;
+    if constexpr (PIPE) {
+      // group g = (kt, s2) = 16 keys.  ONE set of fragment registers, reused on the fly: the two reads of (g + 1, dt) go
+      // out right behind the MFMA that consumed (g, dt), so eight reads stay in flight and the oldest pair is what the
+      // next MFMA needs (group 0 was requested behind QK^T)
+      const uint32_t vl[NDT] = {va_lo[0] + add, va_lo[1] + add, va_lo[2] + add, va_lo[3] + add};
+      const uint32_t vh[NDT] = {va_hi[0] + add, va_hi[1] + add, va_hi[2] + add, va_hi[3] + add};
+      auto pv = [&](auto G) __attribute__((always_inline)) {
+        constexpr int g = decltype(G)::value;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(vb_ + voff_lo[dt]));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(vb_ + voff_hi[dt]));
-          // the transposed read already delivers packed 16-bit pairs: reinterpret, do not repack
-          const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
-          a[dt] = u32x4{lo2.x, lo2.y, hi2.x, hi2.y};
+          if constexpr (g + 1 < 4) lgkm_wait1<2 * NDT - 2>(vlo[0][dt], vhi[0][dt]);
+          else if (dt == 0) lgkm_wait1<6>(vlo[0][dt], vhi[0][dt]);
+          else if (dt == 1) lgkm_wait1<4>(vlo[0][dt], vhi[0][dt]);
+          else if (dt == 2) lgkm_wait1<2>(vlo[0][dt], vhi[0][dt]);
+          else lgkm_wait1<0>(vlo[0][dt], vhi[0][dt]);
+          const u32x4 a = {vlo[0][dt].x, vlo[0][dt].y, vhi[0][dt].x, vhi[0][dt].y};
+          oacc[dt] = mfma<Tag>(a, pf[g >> 1][g & 1], oacc[dt]);
+          if constexpr (g + 1 < 4) {
+            ds_r64tr<BO + (g + 1) * 16 * ROW_BYTES>(vlo[0][dt], vl[dt]);
+            ds_r64tr<BO + (g + 1) * 16 * ROW_BYTES>(vhi[0][dt], vh[dt]);
+          }
         }
-        // four independent accumulators in a row (see QK^T above)
+      };
+      pv(std::integral_constant<int, 0>{});
+      pv(std::integral_constant<int, 1>{});
+      pv(std::integral_constant<int, 2>{});
+      pv(std::integral_constant<int, 3>{});
+    } else {
+      const char *vt = smem + BO + TILE_BYTES;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) oacc[dt] = mfma<Tag>(a[dt], pf[kt][s2], oacc[dt]);
-      }
-    // registers -> the OTHER buffer (last read one iteration ago, behind the previous barrier), then the
-    // single barrier of this tile: publishes tile t+1 and retires every wave's reads of tile t
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile t+1 has landed
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const char *vb_ = vt + (kt * 32 + 16 * s2) * ROW_BYTES;
+          u32x4 a[NDT];
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(vb_ + voff_lo[dt]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(vb_ + voff_hi[dt]));
+            // the transposed read already delivers packed 16-bit pairs: reinterpret, do not repack
+            const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+            a[dt] = u32x4{lo2.x, lo2.y, hi2.x, hi2.y};
+          }
+          // four independent accumulators in a row (see QK^T above)
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) oacc[dt] = mfma<Tag>(a[dt], pf[kt][s2], oacc[dt]);
+        }
+    }
+  };
+  // top of an iteration: the DMA of the next tile into the buffer whose readers all passed the previous barrier
+  auto tile_top = [&](const int t) __attribute__((always_inline)) {
+    // (PIPE: nothing of the prologue — kernel-argument scalar loads included — may still be counted when the first
+    // hand-counted wait runs)
+    if constexpr (PIPE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // global -> another LDS buffer, in flight during this tile's MFMAs  (tried in round 3: issued behind QK^T, in the
+    // VALU-only stretch where an LDS-DMA instruction is cheaper to issue: 862 vs 876 TFLOP/s at 4 x 4096, dropped)
+    if (t + 1 < n_tiles && !(rescale_thr < 0.f && t > 0)) dma(t + 1, (t + 1) % NBUF);   // (thr < 0: bench ablation)
+  };
+  // end of an iteration: this wave's share of tile t+1 has landed, then the single barrier of the tile: it publishes
+  // tile t+1 and retires every wave's reads of the buffer the next DMA will overwrite
+  auto tile_end = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tile_ok = tile_ok_next;
     __syncthreads();
+  };
+  // Tried in round 3 and removed (profiles/r03_prefill_kernel.md): the two waves of a SIMD run half a tile apart (waves
+  // 4-7 defer the PV of a tile to the start of the next iteration, three K|V buffers) so that one wave's softmax runs
+  // beside the other's MFMAs — correct, bit-identical, and SLOWER: 875-895 against 935-942 TFLOP/s at 4 x 4096.
+  auto tile = [&](const int t, auto BUF) __attribute__((always_inline)) {
+    constexpr int BO = decltype(BUF)::value * 2 * TILE_BYTES;   // byte offset of this tile's K|V buffer
+    tile_top(t);
+    qk_phase(std::integral_constant<int, BO>{}, 0u);
+    softmax_phase(t);
+    pv_phase(std::integral_constant<int, BO>{}, 0u);
+    tile_end();
+  };
+  for (int t = 0; t < n_tiles; t += 2) {
+    tile(t, std::integral_constant<int, 0>{});
+    if (t + 1 < n_tiles) tile(t + 1, std::integral_constant<int, 1>{});
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (r,h) owns d = 32dt + 8c + 4h + {0..3}
@@ -343,19 +487,29 @@ int mv_prefill_mfma_launch(const PrefillParams &p, int dtype, int variant, hipSt
   // 8 waves (256 query rows) per workgroup share a K/V tile where the sequences are long enough that the larger
   // blocks still fill the chip evenly; short prompts keep 4 waves x 2 workgroups per CU (measured per shape,
   // profiles/r02_prefill_kernel.md).  variant (bench switch, flags >> 4): 1 = force 4 waves, 2 = force 8
-  const int nw = variant == 1 ? 4 : (variant == 2 ? 8 : (p.max_seqlen_q >= 2048 ? 8 : 4));
+  // round 3: variants 3 / 4 = the round-2 loop (compiler-placed LDS reads) with 4 / 8 waves, for comparison
+  const bool no_defer = (variant & 8) != 0;   // bench switch: rescale on every tile whose maximum moved
+  const bool no_dma = (variant & 16) != 0;    // bench ablation: K/V tiles are not refreshed (results are garbage)
+  variant &= 7;
+  const bool pipe = variant != 3 && variant != 4;
+  // rescale threshold (log2 units): the O accumulator is rescaled only when a row maximum grows by more than a factor of
+  // 2^6 (+5.5 % at 4 x 4096; P then holds values up to 64, well inside bf16 / f16 range; same relative rounding)
+  const float thr = no_dma ? -1.0f : ((pipe && !no_defer) ? 6.0f : 0.0f);
+  const int nw = (variant == 1 || variant == 3) ? 4 : ((variant == 2 || variant == 4) ? 8 : (p.max_seqlen_q >= 2048 ? 8 : 4));
   const int bm = nw * 32;
   const int q_blocks = (p.max_seqlen_q + bm - 1) / bm;
   if (q_blocks == 0 || p.n_seqs == 0) return MV_OK;
   dim3 grid(p.n_heads, p.n_seqs, q_blocks), block(nw * 64);
   const size_t lds = 4 * TILE_BYTES;  // 2 x (K tile + V tile) = 64 KiB -> two workgroups per CU
-#define MV_PF_LAUNCH(NWAVES)                                                                   \
-  do {                                                                                        \
-    if (dtype == MV_BF16) hipLaunchKernelGGL((prefill_mfma_kernel<bf16_tag, NWAVES>), grid, block, lds, stream, p); \
-    else hipLaunchKernelGGL((prefill_mfma_kernel<f16_tag, NWAVES>), grid, block, lds, stream, p);                   \
+#define MV_PF_LAUNCH(NWAVES, PIPED)                                                                            \
+  do {                                                                                                        \
+    if (dtype == MV_BF16) hipLaunchKernelGGL((prefill_mfma_kernel<bf16_tag, NWAVES, PIPED>), grid, block, lds, stream, p, thr); \
+    else hipLaunchKernelGGL((prefill_mfma_kernel<f16_tag, NWAVES, PIPED>), grid, block, lds, stream, p, thr);   \
   } while (0)
-  if (nw == 8) MV_PF_LAUNCH(8);
-  else MV_PF_LAUNCH(4);
+  if (nw == 8 && pipe) MV_PF_LAUNCH(8, true);
+  else if (nw == 8) MV_PF_LAUNCH(8, false);
+  else if (pipe) MV_PF_LAUNCH(4, true);
+  else MV_PF_LAUNCH(4, false);
 #undef MV_PF_LAUNCH
   MV_LAUNCH_CHECK();
   return MV_OK;
