@@ -25,6 +25,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
     ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--skip-last", type=int, default=4,
+                    help="decode steps at the end of the run that are NOT part of the timed loop (bench.py's eager "
+                         "roofline probe: one warm-up + three probe steps)")
     a = ap.parse_args()
     rows = []
     with open(a.trace) as f:
@@ -32,6 +35,8 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     ends = [i for i, r in enumerate(rows) if "sample_kernel" in r[2]]
+    if a.skip_last:
+        ends = ends[:-a.skip_last]
     if len(ends) < a.steps + 1:
         raise SystemExit("not enough sample_kernel dispatches in the trace")
     lo, hi = ends[-a.steps - 1] + 1, ends[-1] + 1
