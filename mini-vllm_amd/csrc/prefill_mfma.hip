@@ -156,6 +156,11 @@ __global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams 
   const int kv_len = min(sk, q_last + shift + 1);
   const int n_tiles = (kv_len + BN - 1) / BN;
   const int wave_qpos_min = shift + qb * BM + wave * 32;  // smallest key limit among this wave's rows
+  // ... and the largest: tiles that start beyond it are masked out for EVERY row of this wave (the workgroup walks the
+  // tiles its LAST wave needs): such a wave skips the tile's arithmetic (p = 0 for all its scores: maximum, sum and
+  // accumulator would not move) and only takes part in the DMA and the barrier.  Waves 0..NW-2 save (NW-1-w)/2 tiles
+  // each: 5 % of the MFMAs at 4096 tokens, 22 % at 1024, more for short prompts.
+  const int wave_qpos_max = wave_qpos_min + 31;
 
   const bool paged = p.block_tables != nullptr;
   const T *ksrc = paged ? (const T *)p.k_cache : (const T *)p.k;
@@ -320,7 +325,7 @@ __global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams 
       }
     }
   };
-  auto softmax_phase = [&](const int t) __attribute__((always_inline)) {
+  auto softmax_phase = [&](const int t, const bool tile_ok) __attribute__((always_inline)) {
     const int kv0 = t * BN;
     // ---- mask (only tiles that touch the diagonal / the ragged end: wave-uniform branch)
     if ((kv0 + BN - 1 > wave_qpos_min) || (kv0 + BN > sk) || !tile_ok) {
@@ -449,12 +454,15 @@ __global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams 
   // Tried in round 3 and removed (profiles/r03_prefill_kernel.md): the two waves of a SIMD run half a tile apart (waves
   // 4-7 defer the PV of a tile to the start of the next iteration, three K|V buffers) so that one wave's softmax runs
   // beside the other's MFMAs — correct, bit-identical, and SLOWER: 875-895 against 935-942 TFLOP/s at 4 x 4096.
+  // (also tried and removed: two tiles per barrier — four K|V buffers, half the barriers: 958-960 against 970-988)
   auto tile = [&](const int t, auto BUF) __attribute__((always_inline)) {
     constexpr int BO = decltype(BUF)::value * 2 * TILE_BYTES;   // byte offset of this tile's K|V buffer
     tile_top(t);
-    qk_phase(std::integral_constant<int, BO>{}, 0u);
-    softmax_phase(t);
-    pv_phase(std::integral_constant<int, BO>{}, 0u);
+    if (t * BN <= wave_qpos_max) {
+      qk_phase(std::integral_constant<int, BO>{}, 0u);
+      softmax_phase(t, tile_ok);
+      pv_phase(std::integral_constant<int, BO>{}, 0u);
+    }
     tile_end();
   };
   for (int t = 0; t < n_tiles; t += 2) {
@@ -490,17 +498,18 @@ int mv_prefill_mfma_launch(const PrefillParams &p, int dtype, int variant, hipSt
   // round 3: variants 3 / 4 = the round-2 loop (compiler-placed LDS reads) with 4 / 8 waves, for comparison
   const bool no_defer = (variant & 8) != 0;   // bench switch: rescale on every tile whose maximum moved
   const bool no_dma = (variant & 16) != 0;    // bench ablation: K/V tiles are not refreshed (results are garbage)
+  const float thr_pick = 6.0f + 2.0f * (float)((variant >> 6) & 3);   // bench switch: rescale threshold 6 / 8 / 10 / 12
   variant &= 7;
   const bool pipe = variant != 3 && variant != 4;
   // rescale threshold (log2 units): the O accumulator is rescaled only when a row maximum grows by more than a factor of
   // 2^6 (+5.5 % at 4 x 4096; P then holds values up to 64, well inside bf16 / f16 range; same relative rounding)
-  const float thr = no_dma ? -1.0f : ((pipe && !no_defer) ? 6.0f : 0.0f);
+  const float thr = no_dma ? -1.0f : ((pipe && !no_defer) ? thr_pick : 0.0f);
   const int nw = (variant == 1 || variant == 3) ? 4 : ((variant == 2 || variant == 4) ? 8 : (p.max_seqlen_q >= 2048 ? 8 : 4));
   const int bm = nw * 32;
   const int q_blocks = (p.max_seqlen_q + bm - 1) / bm;
   if (q_blocks == 0 || p.n_seqs == 0) return MV_OK;
   dim3 grid(p.n_heads, p.n_seqs, q_blocks), block(nw * 64);
-  const size_t lds = 4 * TILE_BYTES;  // 2 x (K tile + V tile) = 64 KiB -> two workgroups per CU
+  const size_t lds = 4 * TILE_BYTES;   // 2 x (K tile + V tile) = 64 KiB -> two workgroups per CU
 #define MV_PF_LAUNCH(NWAVES, PIPED)                                                                            \
   do {                                                                                                        \
     if (dtype == MV_BF16) hipLaunchKernelGGL((prefill_mfma_kernel<bf16_tag, NWAVES, PIPED>), grid, block, lds, stream, p, thr); \
