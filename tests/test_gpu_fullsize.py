@@ -147,3 +147,59 @@ def test_lm_head_small_m_matches_library_gemm(H):
     assert (got == lib).float().mean() > 0.9
     # linearity in x (exact for a power-of-two factor)
     assert torch.equal(H.linear_small_m(x * 2, w).float(), got * 2)
+
+
+# config 3 / 5 sampler shape under tensor parallelism: 256 rows x 151 936 logits over 8 emulated ranks
+def test_two_stage_draw_at_full_size_is_consistent_with_the_full_row(H):
+    """The gather-free draw for the default SamplingParams (mv_mass_pack / mv_mass_merge) at B = 256, V = 151 936, TP = 8,
+    through properties that need no second implementation:
+      * greedy rows: the token is the full row's argmax,
+      * sampled rows: the token is a valid id, and its logit lies inside the numerically reachable set — with the row's
+        uniform u the inverse-CDF draw cannot land on a token whose probability is < 2^-24 of the row's mass,
+      * the shard masses add up to the full row's mass (logsumexp identity, fp32),
+      * the same (seed, offset) gives the same tokens; another offset moves most sampled rows,
+      * a row concentrated on one token (logit + 40) always returns that token."""
+    dtype, B, V, world = torch.bfloat16, 256, 151936, 8
+    vpr = V // world
+    full = _rand((B, V), dtype, 11, 2.0)
+    spike = torch.arange(0, B, 7, device=DEV)
+    spike_tok = (spike * 593 + 17) % V
+    full[spike, spike_tok] = 40.0
+    temps = torch.ones(B, device=DEV)
+    temps[::4] = 0.0                                      # every fourth row greedy
+    temps[1::4] = 0.7
+    ks = torch.full((B,), -1, dtype=torch.int64, device=DEV)
+    ones, zeros = torch.ones(B, device=DEV), torch.zeros(B, device=DEV)
+
+    def draw(offset):
+        bufs, masses, maxes = [], [], []
+        for r in range(world):
+            shard = full[:, r * vpr:(r + 1) * vpr]
+            local, stats = H.sample(shard, temps, ks, ones, zeros, seed=21, offset=offset, return_stats=True)
+            bufs.append(H.mass_pack(stats, local, r, world, vpr, B, dtype))
+            maxes.append(stats[:, 0])
+            masses.append(stats[:, 1])
+        summed = torch.stack([b.float() for b in bufs]).sum(0).to(dtype)
+        return H.mass_merge(summed, B, temps, seed=21, offset=offset), torch.stack(maxes, 1), torch.stack(masses, 1)
+
+    toks, maxes, masses = draw(5)
+    assert toks.shape == (B,) and int(toks.min()) >= 0 and int(toks.max()) < V
+    greedy = temps == 0
+    assert torch.equal(toks[greedy], full[greedy].float().argmax(-1))
+    assert torch.equal(toks[spike], spike_tok)                                   # e^-30 of the mass elsewhere
+    # shard statistics: sum_r S_r exp((m_r - M)/T) == sum_j exp((l_j - M)/T)
+    sampled = ~greedy
+    t = temps[sampled][:, None]
+    M = maxes[sampled].max(dim=1, keepdim=True).values
+    z_shards = (masses[sampled] * torch.exp((maxes[sampled] - M) / t)).sum(1)
+    z_full = torch.exp((full[sampled].float() - M) / t).sum(1)
+    torch.testing.assert_close(z_shards, z_full, rtol=2e-3, atol=0)
+    # the drawn token is not a numerically unreachable one
+    logit = full[sampled].float().gather(1, toks[sampled][:, None]).squeeze(1)
+    assert bool(((logit - M.squeeze(1)) / t.squeeze(1) > -24 * 0.6931 - 1).all())
+    again, _, _ = draw(5)
+    other, _, _ = draw(6)
+    assert torch.equal(again, toks)
+    plain = sampled.clone()
+    plain[spike] = False
+    assert (other[plain] != toks[plain]).float().mean() > 0.9
