@@ -110,3 +110,65 @@ def test_gated_small_m_random_shapes(H, seed):
         h_ref = H.rmsnorm(x, nw, 1e-6)
         out, r_out = H.norm_linear_small_m(x, None, nw, 1e-6, wp, inter, None, gated=True)
         assert torch.equal(out, H.gate_up_silu_small_m(h_ref, w, packed=wp)) and r_out.data_ptr() == x.data_ptr()
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_prefill_mfma_random_shapes(H, seed):
+    """The flash prefill kernel with hand-placed LDS reads (round 3): random sequence counts / lengths / head layouts,
+    contiguous K/V and the paged (prefix-cached) form with ragged uncached suffixes, 4- and 8-wave workgroups, against
+    the oracle; SPIKED scores (one key row of every sequence scaled up, so that a row maximum jumps by far more than the
+    deferred-rescale threshold in the middle of a row's tiles: cdna_hip_programming.md §5.4 rule 26) — and every launch
+    repeated: a hand-counted wait that is one too small shows up as run-to-run differences."""
+    rng = random.Random(3000 + seed)
+    g = torch.Generator().manual_seed(seed)
+    dtype = rng.choice([torch.bfloat16, torch.float16])
+    hkv, grp = rng.choice([(8, 2), (4, 7), (1, 8), (2, 1), (4, 4)])
+    hq, D, bs = hkv * grp, 128, 64
+    n = rng.randint(1, 4)
+    lens = [rng.choice([1, 31, 32, 33, 63, 64, 65, 127, 129, 200, 257, rng.randint(1, 700), rng.randint(300, 1200)]) for _ in range(n)]
+    paged = seed % 2 == 1
+    cached = [(rng.randint(0, (ln - 1) // bs) * bs if paged else 0) for ln in lens]
+    T = sum(lens)
+    q = torch.randn(T, hq, D, generator=g)
+    k = torch.randn(T, hkv, D, generator=g)
+    v = torch.randn(T, hkv, D, generator=g)
+    off = 0
+    for ln in lens:                                            # the spike: one key row per sequence, late in it
+        if ln > 8:
+            k[off + rng.randint(ln // 2, ln - 1)] *= 6.0
+        off += ln
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    cu_k = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    ref = O.prefill_varlen(q, k, v, cu_k, cu_k, D ** -0.5)
+    tol = {torch.bfloat16: dict(rtol=2 ** -6, atol=2 ** -6), torch.float16: dict(rtol=2 ** -9, atol=2 ** -8)}[dtype]
+    if not paged:
+        args = (q.to(DEV), k.to(DEV), v.to(DEV), cu_k.to(DEV), cu_k.to(DEV), max(lens), max(lens), D ** -0.5)
+        kw = {}
+        want = ref
+    else:
+        nblk = [-(-ln // bs) for ln in lens]
+        nb = sum(nblk) + 2
+        perm = torch.randperm(nb, generator=g).tolist()
+        table = torch.full((n, max(nblk)), -1, dtype=torch.int32)
+        kc = torch.zeros(nb, bs, hkv, D, dtype=dtype)
+        vc = torch.zeros_like(kc)
+        it = iter(perm)
+        for i, ln in enumerate(lens):
+            base = int(cu_k[i])
+            for j in range(nblk[i]):
+                blk = next(it)
+                table[i, j] = blk
+                m = min(bs, ln - j * bs)
+                kc[blk, :m] = k[base + j * bs: base + j * bs + m]
+                vc[blk, :m] = v[base + j * bs: base + j * bs + m]
+        qs = [ln - c for ln, c in zip(lens, cached)]
+        cu_q = torch.tensor([0] + list(torch.tensor(qs).cumsum(0)), dtype=torch.int32)
+        sel = torch.cat([torch.arange(int(cu_k[i]) + cached[i], int(cu_k[i + 1])) for i in range(n)])
+        args = (q[sel].to(DEV), None, None, cu_q.to(DEV), cu_k.to(DEV), max(qs), max(lens), D ** -0.5)
+        kw = dict(k_cache=kc.to(DEV), v_cache=vc.to(DEV), block_tables=table.to(DEV))
+        want = ref[sel]
+    for variant in (1, 2):                                     # 4 waves / 8 waves, both with the hand-placed reads
+        outs = [H.prefill_varlen(*args, flags=variant << 4, **kw) for _ in range(3)]
+        torch.testing.assert_close(outs[0].float().cpu(), want, msg=lambda m: f"seed {seed} variant {variant} {dtype} "
+                                   f"heads {hq}/{hkv} lens {lens} cached {cached}: {m}", **tol)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (seed, variant)
