@@ -374,6 +374,29 @@ int mv_mass_pack(const float *stats, const int64_t *local_tokens, int rank, int 
 int mv_mass_merge(const void *buf, const float *temperatures, uint64_t seed, uint64_t offset,
                   const uint64_t *offset_dev, int world, int rows, int rows_padded, int64_t *tokens,
                   int dtype, void *stream);
+/* f2 for NUCLEUS (top_p < 1) and min-p rows with top_k off — the edge of the kept set found across the ranks instead of
+ * the logit gather of embed_head.py:219-229 in front of Sampler.forward (sampling/sampler.py:84-110; top-p keeps a
+ * token while the mass strictly above it is <= p * Z, min-p while prob >= min_p * max prob).  16-bit logits only.
+ *   row_max [rows] fp32: the row's maximum over ALL ranks (MAX all-reduce of the shard maxima).
+ *   mv_shard_key_hist: hist [rows][256] int64 <- this shard's mass per bin, mass = exp((x - max) / T) in 2^-40 fixed
+ *     point; bins count the 16-bit order keys DOWN from key(max): prefix == NULL -> bin = high byte of the offset,
+ *     else only elements whose high byte equals prefix[row], bin = low byte.  Integer sums: after a SUM all-reduce
+ *     every rank holds the same histogram whatever the order of the additions.  Greedy / degenerate rows: zeros.
+ *   mv_nucleus_pick on the SUMMED histogram: level 0 writes state [rows][2] = {budget = p * Z, mass above the chosen
+ *     bin} and prefix [rows] (the last high-byte bin whose strictly-larger mass fits the budget); level 1 continues
+ *     inside that bin and writes floor_out [rows] fp32 = the smallest kept VALUE (raised to max + T ln(min_p) when
+ *     min-p asks for more; -inf for rows with neither filter and for greedy rows).  Ties at the edge are kept whole,
+ *     like mv_sample's top-p.
+ *   mv_mask_below: out[r][i] = logits[r][i] >= floor[r] ? logits[r][i] : -inf (NaN passes through).
+ * Then mv_sample (filters off, statistics on) on the masked shard and mv_mass_pack / mv_mass_merge pick the rank: two
+ * 2 KB-per-row integer all-reduces and 16 bytes per row and rank instead of 2 * V / tp bytes per row and rank. */
+int mv_shard_key_hist(const void *logits_local, int64_t ld, int vocab_local, int rows, const float *row_max,
+                      const float *temperatures, const int32_t *prefix, int64_t *hist, int dtype, void *stream);
+int mv_nucleus_pick(const int64_t *hist, int level, const float *top_ps, const float *min_ps,
+                    const float *temperatures, const float *row_max, int64_t *state, int32_t *prefix,
+                    float *floor_out, int rows, int dtype, void *stream);
+int mv_mask_below(const void *logits, int64_t ld, int vocab_local, int rows, const float *floor_row,
+                  void *out, int64_t ld_out, int dtype, void *stream);
 int mv_topc_pack(const void *logits_local, int64_t ld, int vocab_local, int rank, int world,
                  int64_t vocab_per_rank, int rows, int rows_padded, void *buf, int dtype, void *stream);
 int mv_topc_unpack(const void *buf, int world, int rows, int rows_padded, void *cand_logits,

@@ -850,6 +850,138 @@ __global__ void mass_merge_kernel(const uint16_t *buf, const float *temperatures
   tokens[r] = tq[pick];
 }
 
+
+// ---- nucleus (top-p) / min-p rows of vocabulary-sharded logits -----------------------------------
+// The edge of the nucleus is a property of the whole row: the smallest value v whose strictly-larger mass E(v) still
+// fits p * Z.  The ranks find it together by a two-level radix walk over the 16-bit order keys, counted DOWN from the
+// row's global maximum (offset = key(max) - key(x); level 0 bins the high byte of the offset, level 1 the low byte
+// inside the bin level 0 chose), exchanging one 256-bin histogram of masses per level.  Masses are 2^-40 fixed point
+// in 64-bit integers: integer sums do not depend on the order of the additions, so the LDS atomics, the all-reduce and
+// therefore the edge are bit-identical on every rank, from run to run and for every TP degree.  (A weight below 2^-40
+// of the maximum's counts as nothing: 150 k of them are 1e-7 of the row.)  The edge becomes a per-row floor; the
+// ordinary sampler then runs on the shard with everything below the floor at -inf, and the two-stage draw above
+// (mv_mass_pack / mv_mass_merge) picks the rank.
+constexpr float kFix = 1099511627776.0f;  // 2^40
+
+template <typename Tag>
+__global__ void __launch_bounds__(kThreads) shard_key_hist_kernel(const uint16_t *logits, int64_t ld, int vocab_local,
+                                                                  const float *row_max, const float *temperatures,
+                                                                  const int32_t *prefix, unsigned long long *hist) {
+  typedef typename elem<Tag>::T T;
+  __shared__ unsigned long long h[256];
+  const int rowi = blockIdx.x;
+  if (threadIdx.x < 256) h[threadIdx.x] = 0ull;
+  __syncthreads();
+  const float m = row_max[rowi];
+  const float temp = temperatures ? temperatures[rowi] : 1.0f;
+  if (temp != 0.0f && m > -INFINITY && m < INFINITY) {  // block-uniform (greedy and degenerate rows: all zero)
+    const T *row = (const T *)logits + (int64_t)rowi * ld;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+    const int kmax = (int)make_key<Tag>(elem<Tag>::st(m));
+    const float inv_t = 1.4426950408889634f / fmaxf(temp, 1e-8f);
+    const int want = prefix ? prefix[rowi] : -1;
+    row_foreach<Tag>(row, vocab_local, vec_ok, [&](int i, T raw, bool ok) {
+      int off = kmax - (int)make_key<Tag>(raw);
+      off = off < 0 ? 0 : off;                         // -0.0 against a +0.0 maximum
+      const float w = __builtin_amdgcn_exp2f((elem<Tag>::ld(raw) - m) * inv_t);
+      const bool in = ok && (w == w) && (want < 0 || (off >> 8) == want);
+      const unsigned bin = want < 0 ? (unsigned)(off >> 8) : (unsigned)(off & 255);
+      if (in) atomicAdd(&h[bin], (unsigned long long)(w * kFix));
+    });
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) hist[(int64_t)rowi * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
+// One 256-thread block per row walks a summed histogram.  Level 0: budget = p * Z, prefix = the last high-byte bin
+// whose strictly-larger mass fits it, state = {budget, that mass}.  Level 1: the same walk over the low byte, starting
+// from the carried mass; the value that owns the chosen key is the nucleus floor, raised to the min-p floor
+// (weight >= min_p  <=>  x >= max + T ln(min_p)) when that one is higher.  Rows without either filter get -inf.
+template <typename Tag>
+__global__ void __launch_bounds__(256) nucleus_pick_kernel(const unsigned long long *hist, int level, const float *top_ps,
+                                                           const float *min_ps, const float *temperatures,
+                                                           const float *row_max, unsigned long long *state,
+                                                           int32_t *prefix, float *floor_out) {
+  typedef typename elem<Tag>::T T;
+  __shared__ unsigned long long scan[256];
+  __shared__ unsigned long long carry[2];
+  const int rowi = blockIdx.x, t = threadIdx.x;
+  const unsigned long long own = hist[(int64_t)rowi * 256 + t];
+  scan[t] = own;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {                      // inclusive Hillis-Steele scan
+    const unsigned long long add = t >= d ? scan[t - d] : 0ull;
+    __syncthreads();
+    scan[t] += add;
+    __syncthreads();
+  }
+  const unsigned long long before = scan[t] - own;         // mass of the bins above mine
+  const float top_p = top_ps ? top_ps[rowi] : 1.0f;
+  unsigned long long budget, base;
+  if (level == 0) {
+    const double z = (double)scan[255];
+    budget = (unsigned long long)(fmin(fmax((double)top_p, 0.0), 1.0) * z);
+    base = 0ull;
+  } else {
+    budget = state[2 * rowi];
+    base = state[2 * rowi + 1];
+  }
+  const int fits = __syncthreads_count(base + before <= budget);   // a prefix of the bins: bin 0 always fits
+  const int pick = fits > 0 ? fits - 1 : 0;
+  if (level == 0) {
+    if (t == pick) {
+      state[2 * rowi] = budget;
+      state[2 * rowi + 1] = before;
+      prefix[rowi] = pick;
+    }
+    return;
+  }
+  if (t != pick) return;
+  const float temp = temperatures ? temperatures[rowi] : 1.0f;
+  const float m = row_max[rowi];
+  float fl = -INFINITY;
+  if (temp != 0.0f && m > -INFINITY && m < INFINITY) {
+    if (top_p < 1.0f) {
+      int key = (int)make_key<Tag>(elem<Tag>::st(m)) - (prefix[rowi] * 256 + pick);
+      key = key < 0 ? 0 : key;
+      const uint32_t rawbits = (key & 0x8000) ? (uint32_t)(key & 0x7fff) : (~(uint32_t)key & 0xffffu);
+      fl = elem<Tag>::ld((T)rawbits);
+      if (!(fl == fl)) fl = -INFINITY;                       // the key ran into the NaN encodings: keep everything
+    }
+    const float min_p = min_ps ? min_ps[rowi] : 0.0f;
+    if (min_p > 0.0f) fl = fmaxf(fl, m + fmaxf(temp, 1e-8f) * __logf(fminf(min_p, 1.0f)));
+  }
+  floor_out[rowi] = fl;
+}
+
+template <typename Tag>
+__global__ void __launch_bounds__(256) mask_below_kernel(const uint16_t *in, int64_t ld_in, const float *floor_row,
+                                                         uint16_t *out, int64_t ld_out, int vocab_local, bool vec_ok) {
+  typedef typename elem<Tag>::T T;
+  const int rowi = blockIdx.y;
+  const float fl = floor_row[rowi];
+  const T ninf = elem<Tag>::st(-INFINITY);
+  const uint16_t *src = in + (int64_t)rowi * ld_in;
+  uint16_t *dst = out + (int64_t)rowi * ld_out;
+  auto keep = [&](uint32_t half) -> uint32_t {
+    const float x = elem<Tag>::ld((T)(half & 0xffffu));
+    return (x >= fl || !(x == x)) ? (half & 0xffffu) : (uint32_t)ninf;   // NaN stays NaN: the sampler's business
+  };
+  if (vec_ok) {
+    const int nvec = vocab_local / 8;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < nvec; c += gridDim.x * 256) {
+      u32x4 v = *(const u32x4 *)(src + (int64_t)c * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = keep(v[j]) | (keep(v[j] >> 16) << 16);
+      *(u32x4 *)(dst + (int64_t)c * 8) = v;
+    }
+    for (int i = nvec * 8 + blockIdx.x * 256 + threadIdx.x; i < vocab_local; i += gridDim.x * 256)
+      dst[i] = (uint16_t)keep(src[i]);
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < vocab_local; i += gridDim.x * 256) dst[i] = (uint16_t)keep(src[i]);
+  }
+}
+
 }  // namespace
 
 extern "C" int mv_mass_pack(const float *stats, const int64_t *local_tokens, int rank, int world,
@@ -886,6 +1018,62 @@ extern "C" int mv_mass_merge(const void *buf, const float *temperatures, uint64_
   else
     hipLaunchKernelGGL((mass_merge_kernel<f16_tag>), dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t *)buf, temperatures, seed, offset, offset_dev, world, rows, rows_padded, tokens);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_shard_key_hist(const void *logits_local, int64_t ld, int vocab_local, int rows, const float *row_max,
+                                 const float *temperatures, const int32_t *prefix, int64_t *hist, int dtype,
+                                 void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!logits_local || !row_max || !hist) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (rows < 0 || vocab_local <= 0 || ld < vocab_local) return MV_E_SHAPE;
+  if (dtype == MV_BF16)
+    hipLaunchKernelGGL((shard_key_hist_kernel<bf16_tag>), dim3(rows), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint16_t *)logits_local, ld, vocab_local, row_max, temperatures, prefix,
+                       (unsigned long long *)hist);
+  else
+    hipLaunchKernelGGL((shard_key_hist_kernel<f16_tag>), dim3(rows), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint16_t *)logits_local, ld, vocab_local, row_max, temperatures, prefix,
+                       (unsigned long long *)hist);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_nucleus_pick(const int64_t *hist, int level, const float *top_ps, const float *min_ps,
+                               const float *temperatures, const float *row_max, int64_t *state, int32_t *prefix,
+                               float *floor_out, int rows, int dtype, void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!hist || !state || !prefix || (level == 1 && (!floor_out || !row_max))) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (rows < 0 || (level != 0 && level != 1)) return MV_E_SHAPE;
+  if (dtype == MV_BF16)
+    hipLaunchKernelGGL((nucleus_pick_kernel<bf16_tag>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long *)hist, level, top_ps, min_ps, temperatures, row_max,
+                       (unsigned long long *)state, prefix, floor_out);
+  else
+    hipLaunchKernelGGL((nucleus_pick_kernel<f16_tag>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long *)hist, level, top_ps, min_ps, temperatures, row_max,
+                       (unsigned long long *)state, prefix, floor_out);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_mask_below(const void *logits, int64_t ld, int vocab_local, int rows, const float *floor_row,
+                             void *out, int64_t ld_out, int dtype, void *stream) {
+  if (rows == 0) return MV_OK;
+  if (!logits || !floor_row || !out) return MV_E_NULLPTR;
+  if (dtype != MV_BF16 && dtype != MV_F16) return dtype == MV_F32 ? MV_E_SHAPE : MV_E_DTYPE;
+  if (rows < 0 || rows > 65535 || vocab_local <= 0 || ld < vocab_local || ld_out < vocab_local) return MV_E_SHAPE;
+  const bool vec_ok = mv_aligned16(logits) && mv_aligned16(out) && ld % 8 == 0 && ld_out % 8 == 0;
+  const int gx = (vocab_local / 8 + 255) / 256 > 0 ? (vocab_local / 8 + 255) / 256 : 1;
+  if (dtype == MV_BF16)
+    hipLaunchKernelGGL((mask_below_kernel<bf16_tag>), dim3(gx, rows), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)logits, ld, floor_row, (uint16_t *)out, ld_out, vocab_local, vec_ok);
+  else
+    hipLaunchKernelGGL((mask_below_kernel<f16_tag>), dim3(gx, rows), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)logits, ld, floor_row, (uint16_t *)out, ld_out, vocab_local, vec_ok);
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

@@ -22,7 +22,8 @@ import torch
 from ..config import Config
 from ..layers.sampler import Sampler
 from ..parallel_state import (decode_step_is_native, get_custom_all_reduce as get_custom_allreduce,
-                              get_tensor_parallel_world_size, tp_candidate_tokens, tp_greedy_tokens, tp_mass_tokens)
+                              get_tensor_parallel_world_size, tp_candidate_tokens, tp_greedy_tokens, tp_mass_tokens,
+                              tp_nucleus_tokens)
 from ..utils.context import reset_context, set_context
 from .. import hip_ops
 from .input_builder import BatchInputs, InputBuilder
@@ -72,6 +73,8 @@ class InferenceExecutor:
         self.cand_graphs: dict[int, torch.cuda.CUDAGraph] = {}     # TP > 1: per-rank top-64 candidates (sampled rows with 1 <= top_k <= 64)
         self.mass_graphs: dict[int, torch.cuda.CUDAGraph] = {}     # TP > 1: two-stage draw (rows sampled from the whole vocabulary)
         self._mass_capture = "no"
+        self.nuc_graphs: dict[int, torch.cuda.CUDAGraph] = {}      # TP > 1: cross-rank nucleus / min-p floor + two-stage draw
+        self._nuc_capture = "no"                                   # "no" | "lazy" | "done" (backend collectives inside)
         self._cand_capture = "no"                                  # "no" | "lazy" | "done"
         self.graph_bs: list[int] = []
         self.graph_vars: dict[str, torch.Tensor] = {}
@@ -317,7 +320,8 @@ class InferenceExecutor:
         """How a tensor-parallel batch gets its tokens: 'greedy' (per-rank argmax merge), 'cand' (per-rank top-64
         candidates: every row greedy or with 1 <= top_k <= 64, 16-bit logits), 'mass' (two-stage draw: every row
         greedy or sampled from the whole vocabulary — top_k off, top_p = 1, min_p = 0, the default SamplingParams) or
-        'gather' (all-gather of the [B, V/tp] logits: everything else, i.e. nucleus / min-p / large top-k rows).
+        'nuc' (top_k off everywhere, nucleus / min-p rows present: cross-rank floor, then the two-stage draw) or
+        'gather' (all-gather of the [B, V/tp] logits: everything else, i.e. rows with 64 < top_k < vocab).
         TP = 1: 'gather' (the plain sampler on the full row)."""
         if self.tp_size == 1 or self.sampler is None:
             return "gather"
@@ -331,6 +335,9 @@ class InferenceExecutor:
                 s.temperature == 0 or ((s.top_k <= 0 or s.top_k >= vocab) and s.top_p >= 1.0 and s.min_p <= 0.0)
                 for s in sequences):
             return "mass"       # the default SamplingParams: the whole vocabulary, an exact two-stage draw
+        if self.dtype in (torch.bfloat16, torch.float16) and vocab <= 1 << 24 and self.tp_size <= 16 and all(
+                s.temperature == 0 or s.top_k <= 0 or s.top_k >= vocab for s in sequences):
+            return "nuc"        # top_k off, some rows with top_p < 1 / min_p > 0: the ranks find the floor together
         return "gather"
 
     def _cand_tokens(self, logits_local, t, k, p, m):
@@ -345,6 +352,14 @@ class InferenceExecutor:
         toks = tp_mass_tokens(logits_local, local, t.float().contiguous(), self.sampler.seed, self.sampler.calls + 1,
                               self.sampler.offset_dev)
         return toks
+
+    def _nuc_tokens(self, logits_local, t, k, p, m):
+        """'nuc' mode, eager: the cross-rank floor, then the sampler (filters off, one Philox step) on the masked shard
+        and the 16-byte-per-row exchange."""
+        def local(ll):
+            return self.sampler(ll, temperatures=t, top_ks=None, top_ps=None, min_ps=None, return_stats=True)
+        return tp_nucleus_tokens(logits_local, local, t, p, m, self.sampler.seed, self.sampler.calls + 1,
+                                 self.sampler.offset_dev)
 
     def _greedy_merge(self, logits_local, t, k, p, m):
         """Tokens of an all-greedy batch from this rank's vocab shard (temperature 0 rows: the sampler
@@ -369,6 +384,8 @@ class InferenceExecutor:
             return self._cand_tokens(logits, t, k, p, m).tolist()
         if mode == "mass":
             return self._mass_tokens(logits, t, k, p, m).tolist()
+        if mode == "nuc":
+            return self._nuc_tokens(logits, t, k, p, m).tolist()
         return self.sampler(logits, temperatures=t, top_ks=k, top_ps=p, min_ps=m).tolist()
 
     def _update_metrics(self, sequences, prefill: bool) -> None:
@@ -401,6 +418,13 @@ class InferenceExecutor:
                 return "cand", self.cand_graphs
         if mode == "mass" and self.mass_graphs:
             return "mass", self.mass_graphs
+        if mode == "nuc":
+            if self._nuc_capture == "lazy" and capture:
+                self._drop_speculation()
+                torch.cuda.synchronize(self.device)
+                self._capture_nuc()
+            # (no graphs: the step runs eagerly in 'nuc' mode -- _graph_bucket finds no bucket in an empty family)
+            return "nuc", self.nuc_graphs
         if capture and self._general_capture == "lazy":
             self._drop_speculation()
             torch.cuda.synchronize(self.device)
@@ -461,6 +485,7 @@ class InferenceExecutor:
                     # the gathered-logits family needs RCCL nodes in its graphs: captured on the first batch with
                     # a sampled row (_graph_bucket), so that a greedy-only workload never captures a collective
                     self._general_capture = "lazy"
+                    self._nuc_capture = "lazy"      # same reason: three small backend all-reduces inside
             if self._general_capture == "done":
                 self._capture_general()
             logger.info("Captured %d decode graphs (batch sizes %s..%d)", len(self.graphs) + len(self.greedy_graphs),
@@ -471,8 +496,9 @@ class InferenceExecutor:
             self.greedy_graphs.clear()
             self.cand_graphs.clear()
             self.mass_graphs.clear()
+            self.nuc_graphs.clear()
             self.graph_pool = None
-            self._general_capture = self._cand_capture = self._mass_capture = "no"
+            self._general_capture = self._cand_capture = self._mass_capture = self._nuc_capture = "no"
             self._recover_from_failed_capture()
 
     def _capture_general(self) -> None:
@@ -531,6 +557,19 @@ class InferenceExecutor:
             self._mass_capture = "no"
             self._recover_from_failed_capture()
 
+    def _capture_nuc(self) -> None:
+        """The cross-rank-floor graphs (batches with nucleus / min-p rows and top_k off under TP), on first use."""
+        self._neutralise_graph_inputs()
+        try:
+            for bs in reversed(self.graph_bs):
+                self._capture_one(bs, mode="nuc")
+            self._nuc_capture = "done"
+        except Exception as e:
+            logger.warning("Failed to capture the nucleus-floor graphs (such batches decode eagerly): %s", e)
+            self.nuc_graphs.clear()
+            self._nuc_capture = "no"
+            self._recover_from_failed_capture()
+
     def _recover_from_failed_capture(self) -> None:
         reset_context()
         # a failed capture leaves torch's side capture stream current (torch.cuda.graph.__exit__
@@ -567,6 +606,12 @@ class InferenceExecutor:
             toks = tp_mass_tokens(out, lambda ll: hip_ops.sample(
                 ll, d[0, :bs], self._dev_samp_i64[:bs], d[1, :bs], d[2, :bs], seed=self.sampler.seed, offset=0,
                 offset_dev=gv["rng_offset"], return_stats=True), d[0, :bs], self.sampler.seed, 0, gv["rng_offset"])
+        elif mode == "nuc":   # TP > 1, top_k off, nucleus / min-p rows: cross-rank floor, masked two-stage draw
+            out = gv["logits_local"][:bs]
+            out.copy_(self.model.compute_logits(hidden, gather=False))
+            toks = tp_nucleus_tokens(out, lambda ll: hip_ops.sample(
+                ll, d[0, :bs], None, None, None, seed=self.sampler.seed, offset=0, offset_dev=gv["rng_offset"],
+                return_stats=True), d[0, :bs], d[1, :bs], d[2, :bs], self.sampler.seed, 0, gv["rng_offset"])
         else:
             out = gv["logits"][:bs]
             out.copy_(self.model.compute_logits(hidden))
@@ -590,7 +635,8 @@ class InferenceExecutor:
             self._graph_forward(bs, mode=mode)
         if self.graph_pool is None:
             self.graph_pool = graph.pool()
-        {"greedy": self.greedy_graphs, "cand": self.cand_graphs, "mass": self.mass_graphs, "gather": self.graphs}[mode][bs] = graph
+        {"greedy": self.greedy_graphs, "cand": self.cand_graphs, "mass": self.mass_graphs, "nuc": self.nuc_graphs,
+         "gather": self.graphs}[mode][bs] = graph
         torch.cuda.synchronize(self.device)
         reset_context()
 
@@ -679,6 +725,7 @@ class InferenceExecutor:
         self.greedy_graphs.clear()
         self.cand_graphs.clear()
         self.mass_graphs.clear()
+        self.nuc_graphs.clear()
         self.graph_vars.clear()
         self.graph_pool = None
         self.kv_cache = None

@@ -98,6 +98,10 @@ _SIGNATURES = {
     "mv_topc_width": (c_int, []),
     "mv_topc_pack": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mv_topc_unpack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "mv_shard_key_hist": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "mv_nucleus_pick": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_int, c_int, c_void_p]),
+    "mv_mask_below": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mv_topc_pick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -701,6 +705,50 @@ def mass_merge(buf, rows: int, temperatures, seed: int = 0, offset: int = 0, off
     _check(_lib.mv_mass_merge(buf.data_ptr(), _ptr(temperatures), int(seed) & (2**64 - 1), int(offset) & (2**64 - 1),
                               _ptr(offset_dev), world, rows, rows_padded, out.data_ptr(), _dt(buf), _stream()),
            "mv_mass_merge")
+    return out
+
+
+def shard_key_hist(logits_local, row_max, temperatures, prefix=None):
+    """-> int64 [rows, 256]: this shard's fixed-point mass per key bin below the row's global maximum (mv_shard_key_hist)."""
+    _need_cuda(logits_local, row_max, temperatures, prefix)
+    rows, vl = logits_local.shape
+    assert logits_local.stride(1) == 1 and row_max.dtype == torch.float32 and row_max.is_contiguous()
+    assert temperatures is None or (temperatures.dtype == torch.float32 and temperatures.is_contiguous())
+    assert prefix is None or (prefix.dtype == torch.int32 and prefix.is_contiguous())
+    hist = torch.empty((rows, 256), dtype=torch.int64, device=logits_local.device)
+    _check(_lib.mv_shard_key_hist(logits_local.data_ptr(), logits_local.stride(0), vl, rows, row_max.data_ptr(),
+                                  _ptr(temperatures), _ptr(prefix), hist.data_ptr(), _dt(logits_local), _stream()),
+           "mv_shard_key_hist")
+    return hist
+
+
+def nucleus_pick(hist, level: int, top_ps, min_ps, temperatures, row_max, dtype, state=None, prefix=None):
+    """Level 0 -> (state int64 [rows, 2], prefix int32 [rows]); level 1 (with those) -> floor fp32 [rows]
+    (mv_nucleus_pick; ``hist`` = the all-reduced ``shard_key_hist`` of that level)."""
+    _need_cuda(hist, top_ps, min_ps, temperatures, row_max)
+    rows = hist.shape[0]
+    assert hist.dtype == torch.int64 and hist.shape == (rows, 256) and hist.is_contiguous()
+    for x in (top_ps, min_ps, temperatures, row_max):
+        assert x is None or (x.dtype == torch.float32 and x.is_contiguous())
+    dev = hist.device
+    if level == 0:
+        state = torch.empty((rows, 2), dtype=torch.int64, device=dev)
+        prefix = torch.empty((rows,), dtype=torch.int32, device=dev)
+    floor = torch.empty((rows,), dtype=torch.float32, device=dev) if level == 1 else None
+    _check(_lib.mv_nucleus_pick(hist.data_ptr(), level, _ptr(top_ps), _ptr(min_ps), _ptr(temperatures), _ptr(row_max),
+                                state.data_ptr(), prefix.data_ptr(), _ptr(floor), rows, _DTYPES[dtype], _stream()),
+           "mv_nucleus_pick")
+    return (state, prefix) if level == 0 else floor
+
+
+def mask_below(logits, floor):
+    """-> copy of ``logits`` [rows, V] with everything below the row's ``floor`` (fp32 [rows]) at -inf (mv_mask_below)."""
+    _need_cuda(logits, floor)
+    rows, vl = logits.shape
+    assert logits.stride(1) == 1 and floor.dtype == torch.float32 and floor.is_contiguous()
+    out = torch.empty((rows, vl), dtype=logits.dtype, device=logits.device)
+    _check(_lib.mv_mask_below(logits.data_ptr(), logits.stride(0), vl, rows, floor.data_ptr(), out.data_ptr(),
+                              out.stride(0), _dt(logits), _stream()), "mv_mask_below")
     return out
 
 

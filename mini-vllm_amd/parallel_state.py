@@ -164,6 +164,36 @@ def tp_mass_tokens(logits_local: torch.Tensor, sample_stats_fn, temperatures: to
     return hip_ops.mass_merge(buf, n, temperatures, seed, offset, offset_dev)
 
 
+def tp_nucleus_tokens(logits_local: torch.Tensor, sample_stats_fn, temperatures: torch.Tensor, top_ps: torch.Tensor,
+                      min_ps: torch.Tensor, seed: int, offset: int, offset_dev=None) -> torch.Tensor:
+    """Tokens of rows with a nucleus (top_p < 1) and / or a min-p filter and top_k off (plus greedy / unfiltered rows
+    in the same batch) without the logit gather.  The ranks find the edge of the kept set together:
+    the row maximum (MAX all-reduce of B floats), then a two-level radix walk over the 16-bit order keys below it with
+    one all-reduced 256-bin histogram of fixed-point masses per level (mv_shard_key_hist / mv_nucleus_pick: integer
+    sums, so every rank derives the same floor); every rank masks its shard below the floor and the batch finishes as
+    ``tp_mass_tokens`` does -- ``sample_stats_fn(masked shard)`` must run the sampler with its filters OFF."""
+    from . import hip_ops
+
+    n, vpr = logits_local.shape
+    group = _state["group"]
+    t32 = temperatures.float().contiguous()
+    p32 = top_ps.float().contiguous()
+    m32 = min_ps.float().contiguous()
+    row_max = logits_local.amax(dim=1).float()
+    dist.all_reduce(row_max, op=dist.ReduceOp.MAX, group=group)
+    hist = hip_ops.shard_key_hist(logits_local, row_max, t32, None)
+    dist.all_reduce(hist, group=group)
+    state, prefix = hip_ops.nucleus_pick(hist, 0, p32, m32, t32, row_max, logits_local.dtype)
+    hist = hip_ops.shard_key_hist(logits_local, row_max, t32, prefix)
+    dist.all_reduce(hist, group=group)
+    floor = hip_ops.nucleus_pick(hist, 1, p32, m32, t32, row_max, logits_local.dtype, state, prefix)
+    masked = hip_ops.mask_below(logits_local, floor)
+    local, stats = sample_stats_fn(masked)
+    buf = hip_ops.mass_pack(stats, local, _state["rank"], _state["size"], vpr, n, logits_local.dtype)
+    tp_all_reduce(buf.view(-1))
+    return hip_ops.mass_merge(buf, n, t32, seed, offset, offset_dev)
+
+
 def decode_step_is_native(dtype: torch.dtype, hidden_size: int, vocab_size: int) -> bool:
     """True when an all-greedy decode step of a model with these dimensions needs no backend collective: every
     all-reduce and the greedy exchange run on this library's peer-to-peer kernel (-> the step captures into a

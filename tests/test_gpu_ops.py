@@ -660,6 +660,91 @@ def test_mass_two_stage_draw_is_the_full_row_softmax(H, dtype, world):
     assert (counts[2] > 0).sum() == 1                                           # the greedy row never moves
 
 
+def _emulated_nucleus_floor(H, full, world, temps, top_ps, min_ps):
+    """The cross-rank walk of tp_nucleus_tokens with the ranks emulated on one device (the all-reduces are host sums)."""
+    B, vocab = full.shape
+    vpr = vocab // world
+    shards = [full[:, r * vpr:(r + 1) * vpr].contiguous() for r in range(world)]
+    row_max = torch.stack([s.amax(dim=1).float() for s in shards]).amax(dim=0)
+    h0 = sum(H.shard_key_hist(s, row_max, temps, None) for s in shards)
+    state, prefix = H.nucleus_pick(h0, 0, top_ps, min_ps, temps, row_max, full.dtype)
+    h1 = sum(H.shard_key_hist(s, row_max, temps, prefix) for s in shards)
+    floor = H.nucleus_pick(h1, 1, top_ps, min_ps, temps, row_max, full.dtype, state, prefix)
+    return shards, row_max, h0, floor
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("world", [2, 8])
+def test_nucleus_floor_across_shards_is_the_full_row_keep_mask(H, dtype, world):
+    """f2 for nucleus / min-p rows: the floor the emulated ranks agree on keeps exactly the set mv_sample keeps on the
+    full row (its keep mask is the oracle-checked one), for peaked and flat rows, top-p alone, min-p alone and both;
+    the level-0 histogram sums to the row's mass; greedy and unfiltered rows get -inf."""
+    vocab, B = 1024 * world, 8
+    g = torch.Generator().manual_seed(300 + world)
+    full = torch.randn(B, vocab, generator=g)
+    full[:4] *= 3.0                                   # peaked rows
+    full[4:] *= 0.3                                   # flat rows: the edge lies deep in the row
+    full = full.to(dtype).to(DEV)
+    temps = torch.tensor([1.0, 0.7, 1.0, 0.0, 1.0, 1.5, 1.0, 1.0], device=DEV)
+    top_ps = torch.tensor([0.9, 0.5, 1.0, 0.9, 0.95, 0.3, 1.0, 0.999], device=DEV)
+    min_ps = torch.tensor([0.0, 0.0, 0.05, 0.0, 0.0, 0.2, 0.0, 0.5], device=DEV)
+    ks = torch.full((B,), -1, dtype=torch.int64, device=DEV)
+    shards, row_max, h0, floor = _emulated_nucleus_floor(H, full, world, temps, top_ps, min_ps)
+    assert torch.equal(row_max, full.float().amax(dim=1))
+    z = ((full.double() - row_max.double()[:, None]) / temps.double().clamp_min(1e-8)[:, None]).exp().sum(1)
+    live = temps > 0
+    torch.testing.assert_close(h0.sum(1).double()[live] / 2.0 ** 40, z[live], rtol=1e-5, atol=0)
+    assert (h0[~live] == 0).all()
+    assert floor[3].item() == float("-inf") and floor[6].item() == float("-inf")
+    _, mask = H.sample(full, temps, ks, top_ps, min_ps, seed=1, offset=1, return_mask=True)
+    for b in range(B):
+        if temps[b] == 0:
+            continue
+        mine = full[b].float() >= floor[b]
+        assert torch.equal(mine, mask[b].bool()), (b, int(mine.sum()), int(mask[b].sum()))
+    masked = torch.cat([H.mask_below(s, floor) for s in shards], dim=1)
+    assert torch.equal(masked, torch.where(full.float() >= floor[:, None], full, torch.full_like(full, float("-inf"))))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_nucleus_draw_across_shards_follows_the_filtered_softmax(H, world):
+    """The whole gather-free nucleus sequence (floor -> masked shards -> local draws with statistics -> rank pick) with
+    the ranks emulated on one device: every token lies in the kept set and 6 000 draws per row pass a chi-square
+    against the renormalised softmax over it."""
+    dtype = torch.bfloat16
+    vocab, B = 96 * world, 3
+    vpr = vocab // world
+    g = torch.Generator().manual_seed(400 + world)
+    full = (torch.randn(B, vocab, generator=g) * 2).to(dtype).to(DEV)
+    temps = torch.tensor([1.0, 0.8, 1.2], device=DEV)
+    top_ps = torch.tensor([0.8, 1.0, 0.6], device=DEV)
+    min_ps = torch.tensor([0.0, 0.1, 0.02], device=DEV)
+    ks = torch.full((B,), -1, dtype=torch.int64, device=DEV)
+    shards, _, _, floor = _emulated_nucleus_floor(H, full, world, temps, top_ps, min_ps)
+    masked = [H.mask_below(s, floor) for s in shards]
+    n_draws = 6000
+    counts = torch.zeros(B, vocab, dtype=torch.float64)
+    for off in range(n_draws):
+        bufs = []
+        for r in range(world):
+            local, stats = H.sample(masked[r], temps, None, None, None, seed=5, offset=off, return_stats=True)
+            bufs.append(H.mass_pack(stats, local, r, world, vpr, B, dtype))
+        summed = torch.stack([b.float() for b in bufs]).sum(0).to(dtype)
+        counts[torch.arange(B), H.mass_merge(summed, B, temps, seed=5, offset=off).cpu()] += 1
+    _, mask = H.sample(full, temps, ks, top_ps, min_ps, seed=1, offset=1, return_mask=True)
+    for b in range(B):
+        keep = mask[b].bool().cpu()
+        assert counts[b][~keep].sum() == 0
+        p = torch.softmax(full[b].double().cpu() / float(temps[b]), dim=-1) * keep
+        p = p / p.sum()
+        cells = p * n_draws >= 5
+        exp = torch.cat([p[cells] * n_draws, (p[~cells].sum() * n_draws).view(1)])
+        obs = torch.cat([counts[b][cells], counts[b][~cells].sum().view(1)])
+        chi2 = (((obs - exp) ** 2) / exp.clamp_min(1e-9)).sum().item()
+        dof = int(cells.sum())
+        assert chi2 < dof + 5 * (2 * dof) ** 0.5, (b, chi2, dof)
+
+
 # ------------------------------------------------------------------ K10
 def _ulp_ok(got, exact, dtype, ulps):
     """|got - exact| <= ulps units in the last place of ``dtype`` at the magnitude of ``exact``

@@ -102,6 +102,57 @@ def _worker(rank, port, out_path):
         err = f"{type(e).__name__}: {e}"
     res["rccl_in_graph_capture"] = captured
     res["capture_error"] = err[:500]
+
+    # the gather-free nucleus sequence (parallel_state.tp_nucleus_tokens): its MAX all-reduce of fp32 and its two SUM
+    # all-reduces of int64 histograms are RCCL calls of kinds the step above does not contain -- eager, then captured
+    from minivllm_amd import parallel_state
+
+    parallel_state.init_tensor_parallel(0, 1)
+    B = 64
+    ll = logits_local[:B].contiguous()
+    temps = torch.full((B,), 0.8, device=dev)
+    temps[::7] = 0.0
+    top_ps = torch.full((B,), 0.9, device=dev)
+    min_ps = torch.zeros(B, device=dev)
+    min_ps[1::5] = 0.05
+    rng = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def nuc_step():
+        return parallel_state.tp_nucleus_tokens(
+            ll, lambda m: hip_ops.sample(m, temps, None, None, None, seed=3, offset=0, offset_dev=rng, return_stats=True),
+            temps, top_ps, min_ps, 3, 0, rng)
+
+    try:
+        want = []
+        for i in range(3):
+            rng.fill_(i + 1)
+            want.append(nuc_step().clone())
+        torch.cuda.synchronize()
+        _, mask = hip_ops.sample(ll, temps, torch.full((B,), -1, dtype=torch.int64, device=dev), top_ps, min_ps,
+                                 seed=1, offset=1, return_mask=True)
+        res["nucleus_tokens_inside_the_kept_set"] = bool(all(
+            mask[torch.arange(B, device=dev), w].bool().all() for w in want))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            nuc_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph2):
+            toks = nuc_step()
+        ok = True
+        for i in range(3):
+            rng.fill_(i + 1)
+            graph2.replay()
+            torch.cuda.synchronize()
+            ok &= bool(torch.equal(toks, want[i]))
+        res["nucleus_graph_replays_equal_eager"] = ok
+        res["nucleus_error"] = ""
+    except Exception as e:
+        res["nucleus_graph_replays_equal_eager"] = False
+        res["nucleus_error"] = f"{type(e).__name__}: {e}"[:500]
+    parallel_state.reset_tensor_parallel()
     with open(out_path, "w") as f:
         json.dump(res, f)
     try:
@@ -126,3 +177,6 @@ def test_world1_nccl_bootstrap_and_collectives_in_a_graph(tmp_path):
     # the finding DESIGN.md §5 records; the gathered-logits graph family relies on it
     assert res["rccl_in_graph_capture"], res["capture_error"]
     assert res["graph_replays_equal_eager"] and res["graph_all_gather_ok"]
+    # the nucleus-floor family (MAX of fp32, SUM of int64 through RCCL) captures and replays too
+    assert res["nucleus_error"] == "" and res["nucleus_tokens_inside_the_kept_set"]
+    assert res["nucleus_graph_replays_equal_eager"]

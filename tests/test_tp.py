@@ -469,7 +469,8 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
             real_mode = ex._tp_mode
             ex._tp_mode = lambda seqs: (modes.add(real_mode(seqs)), real_mode(seqs))[1]
             out = [o_["token_ids"] for o_ in llm.generate(prompts, sp, use_tqdm=False)]
-            run.last = dict(modes=modes, cand_graphs=bool(ex.cand_graphs), mass_graphs=bool(ex.mass_graphs))
+            run.last = dict(modes=modes, cand_graphs=bool(ex.cand_graphs), mass_graphs=bool(ex.mass_graphs),
+                            nuc_graphs=bool(ex.nuc_graphs))
             return out, bool(ex.greedy_graphs), ex.spec_hits, parallel_state.get_custom_all_reduce() is not None
         finally:
             llm.exit()
@@ -530,3 +531,16 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
     m_graph, _, _, p2p = run(2, "bfloat16", eager=False, sp=mixed, max_num_seqs=len(prompts))
     if p2p:
         assert run.last["mass_graphs"] and run.last["modes"] == {"mass"} and m_graph == m_eager
+    # nucleus / min-p rows with top_k off (temperature + top_p: the usual serving configuration), 16-bit logits: the ranks
+    # find the floor of the kept set together (row maximum, two all-reduced integer histograms: mv_shard_key_hist /
+    # mv_nucleus_pick), mask their shards and finish with the two-stage draw.  The mode ran, both ranks drew the same
+    # tokens, the greedy row is the all-greedy run's; floor and distribution are checked in tests/test_gpu_ops.py.
+    # (gloo collectives cannot be captured: this family replays graphs on RCCL only -- tests/test_gpu_rccl.py)
+    nuc = [SamplingParams(temperature=0.8, top_p=0.9, max_tokens=12, ignore_eos=True),
+           SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True),
+           SamplingParams(temperature=1.0, min_p=0.1, max_tokens=12, ignore_eos=True)]
+    n_eager = run(2, "bfloat16", sp=nuc, max_num_seqs=len(prompts))[0]
+    assert run.last["modes"] == {"nuc"} and [len(t) for t in n_eager] == [12] * len(prompts)
+    assert all(0 <= t < 320 for row in n_eager for t in row)
+    assert n_eager[1] == a[1]
+    assert run(2, "bfloat16", sp=nuc, max_num_seqs=len(prompts))[0] == n_eager      # integer masses: run-to-run identical
