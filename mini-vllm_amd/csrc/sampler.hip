@@ -215,29 +215,11 @@ __device__ __forceinline__ void row_foreach(const typename elem<Tag>::T *row, in
   }
 }
 
-// LDS histogram add with a cheap wave-level pre-aggregation: logits share a
-// handful of exponents, so in the top digit most lanes of a wave hit the same
-// bin; two "leader bin" rounds take those out before the plain atomics.
+// LDS histogram add: a plain LDS atomic.  (Rounds 1-2 took the wave's most common bins out first with a ballot /
+// broadcast / wave-sum "leader" step; measured on gfx950 that cost more than the same-address serialisation it avoided:
+// the radix paths ran 1.1-3.1x faster without it, profiles/r03_nucleus_sequence_us.json.)
 template <typename V>
 __device__ __forceinline__ void hist_add(V *hist, bool active, unsigned bin, V val) {
-#pragma unroll
-  for (int round = 0; round < 2; ++round) {
-    const unsigned long long m = __ballot(active);
-    if (m == 0) return;
-    const int leader = __ffsll((long long)m) - 1;
-    const unsigned lb = __shfl((int)bin, leader, 64);
-    const bool mine = active && bin == lb;
-    V part = mine ? val : (V)0;
-    // wave_sum for float, integer butterfly for counts
-    if constexpr (__is_same(V, float)) {
-      part = wave_sum(part);
-    } else {
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
-    }
-    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lb], part);
-    active = active && !mine;
-  }
   if (active) atomicAdd(&hist[bin], val);
 }
 
