@@ -1,5 +1,9 @@
 #!/bin/bash
 set -o pipefail
-python -m pytest tests -m gpu -x -q > gpurun_out/r3q_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r3q_pytest.log
-MINIVLLM_TP_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/r3q_bench_tp2.log 2> gpurun_out/r3q_bench_tp2.err; echo "bench tp2 rc=$?"; tail -c 1500 gpurun_out/r3q_bench_tp2.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+mkdir -p gpurun_out
+timeout -k 10 600 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q -k "prefill_mfma_random" > gpurun_out/r3q_pytest.log 2>&1
+echo "rc=$?" >> gpurun_out/r3q_pytest.log
+tail -25 gpurun_out/r3q_pytest.log
+grep -q "rc=0" gpurun_out/r3q_pytest.log || exit 1
+timeout -k 10 300 python tools/bench_kernels.py --prefill-only --variants 0,5 > gpurun_out/r3q_bench.log 2>&1
+tail -30 gpurun_out/r3q_bench.log
