@@ -314,44 +314,69 @@ __global__ void __launch_bounds__(256) paged_decode_kernel(DecodeParams p) {
   }
 }
 
-// Split-KV combine: one workgroup per (sequence, head), one thread per output dim.  The (m, l) pairs
-// go through LDS once; the partial rows are then summed with independent, unrolled loads (the serial
-// "load, scale, add" chain of a naive loop costs one L2 round trip per split: 10 us at 32 splits).
+// Split-KV combine: one workgroup (128 threads) per (sequence, head).  The partial rows were written by workgroups on other
+// XCDs, so every load is a ~2 us round trip and what counts is how many of them are DEPENDENT: the (m, l) pairs go
+// through LDS once; then thread (q, c) — q = threadIdx / (D/4) picks every QUARTER-th split, c the 16-byte column piece —
+// keeps all its rows (up to 16) in flight at once, and the four partial sums meet in LDS.  (Round 2: one thread per
+// output dim, eight 4-byte loads in flight, four rounds at 32 splits: 6.8 us per launch, 14 % of the B = 1 step.)
 template <typename Tag, int D>
-__global__ void __launch_bounds__(D) paged_decode_reduce_kernel(const float *__restrict__ ws_acc,
-                                                                const float *__restrict__ ws_ml,
-                                                                typename elem<Tag>::T *__restrict__ out,
-                                                                int nsplit) {
-  __shared__ float sm[64], sl[64];  // kMaxSplits
+__global__ void __launch_bounds__(128) paged_decode_reduce_kernel(const float *__restrict__ ws_acc,
+                                                                  const float *__restrict__ ws_ml,
+                                                                  typename elem<Tag>::T *__restrict__ out,
+                                                                  int nsplit) {
+  constexpr int D4 = D / 4, NQ = 128 / D4;    // column pieces; split groups (4 at D = 128, 8 at D = 64)
+  constexpr int kMax = 64, PER = kMax / NQ;   // kMaxSplits; rows per thread at most
+  __shared__ float sf[kMax];
+  __shared__ float s_l;
+  __shared__ f32x4 part[NQ][D4];
   const int64_t bh = blockIdx.x;
-  const int d = threadIdx.x;
-  if (d < nsplit) {
-    sm[d] = ws_ml[(bh * nsplit + d) * 2];
-    sl[d] = ws_ml[(bh * nsplit + d) * 2 + 1];
+  const int tid = threadIdx.x, q = tid / D4, c = tid - q * D4;
+  // rows first (they do not depend on the factors), then the pairs: one round trip covers both
+  f32x4 a[PER];
+  const f32x4 *row = reinterpret_cast<const f32x4 *>(ws_acc + bh * nsplit * D) + c;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int sp = q + u * NQ;
+    a[u] = row[(int64_t)(sp < nsplit ? sp : 0) * D4];
+  }
+  float m = -1e30f, l = 0.f;
+  if (tid < nsplit) {
+    m = ws_ml[(bh * nsplit + tid) * 2];
+    l = ws_ml[(bh * nsplit + tid) * 2 + 1];
+  }
+  // maximum over the splits (<= 64: the first wave holds them all), factors, the sum of l * f
+  if (tid < 64) {
+    float M = m;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+    const float f = tid < nsplit ? __builtin_amdgcn_exp2f(m - M) : 0.f;
+    sf[tid] = f;
+    float L = l * f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) L += __shfl_xor(L, off, 64);
+    if (tid == 0) s_l = L;
   }
   __syncthreads();
-  float M = -1e30f;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, sm[s]);
-  float L = 0.f, A = 0.f;
-  const float *row = ws_acc + bh * nsplit * D + d;
-  int s = 0;
-  for (; s + 8 <= nsplit; s += 8) {
-    float a[8];
+  f32x4 A = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = row[(int64_t)(s + u) * D];
+  for (int u = 0; u < PER; ++u) {
+    const int sp = q + u * NQ;
+    const float f = sp < nsplit ? sf[sp] : 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float f = __builtin_amdgcn_exp2f(sm[s + u] - M);
-      L += sl[s + u] * f;
-      A += a[u] * f;
-    }
+    for (int e = 0; e < 4; ++e) A[e] += a[u][e] * f;
   }
-  for (; s < nsplit; ++s) {
-    const float f = __builtin_amdgcn_exp2f(sm[s] - M);
-    L += sl[s] * f;
-    A += row[(int64_t)s * D] * f;
+  part[q][c] = A;
+  __syncthreads();
+  if (q == 0) {
+#pragma unroll
+    for (int g = 1; g < NQ; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) A[e] += part[g][c][e];
+    const float L = s_l;
+    typename elem<Tag>::T *o = out + bh * D + 4 * c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = elem<Tag>::st(L > 0.f ? A[e] / L : 0.f);
   }
-  out[bh * D + d] = elem<Tag>::st(L > 0.f ? A / L : 0.f);
 }
 
 // ---- host side -------------------------------------------------------------
@@ -467,7 +492,7 @@ int launch_d(const DecodeParams &p, const DecodePlan &pl, int batch, int dtype, 
     const int rc = mv_paged_decode_mfma_launch(p, pl.n_chunks, pl.nsplit, batch, dtype, klds, stream);
     if (rc != MV_OK) return rc;
     if (pl.nsplit > 1) {
-      hipLaunchKernelGGL((paged_decode_reduce_kernel<Tag, D>), dim3(batch * p.n_heads), dim3(D), 0,
+      hipLaunchKernelGGL((paged_decode_reduce_kernel<Tag, D>), dim3(batch * p.n_heads), dim3(128), 0,
                          stream, p.ws_acc, p.ws_ml, (typename elem<Tag>::T *)p.out, pl.nsplit);
       MV_LAUNCH_CHECK();
     }
@@ -486,7 +511,7 @@ int launch_d(const DecodeParams &p, const DecodePlan &pl, int batch, int dtype, 
   }
   MV_LAUNCH_CHECK();
   if (pl.nsplit > 1) {
-    hipLaunchKernelGGL((paged_decode_reduce_kernel<Tag, D>), dim3(batch * p.n_heads), dim3(D), 0,
+    hipLaunchKernelGGL((paged_decode_reduce_kernel<Tag, D>), dim3(batch * p.n_heads), dim3(128), 0,
                        stream, p.ws_acc, p.ws_ml, (typename elem<Tag>::T *)p.out, pl.nsplit);
     MV_LAUNCH_CHECK();
   }
