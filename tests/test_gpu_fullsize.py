@@ -203,3 +203,46 @@ def test_two_stage_draw_at_full_size_is_consistent_with_the_full_row(H):
     plain = sampled.clone()
     plain[spike] = False
     assert (other[plain] != toks[plain]).float().mean() > 0.9
+
+
+def test_nucleus_floor_at_full_size_equals_the_full_row_keep_mask(H):
+    """The cross-rank nucleus / min-p floor (mv_shard_key_hist / mv_nucleus_pick) at B = 256, V = 151 936, TP = 8 (ranks
+    emulated: the all-reduces are host sums of the int64 histograms), against the one thing that must hold at any size:
+    the kept set {x >= floor} of every row IS mv_sample's keep mask on the full row (whose own parity with the reference
+    sampler is pinned at fixture size), for peaked and flat rows and a mix of top-p, min-p, both, none and greedy rows;
+    plus: integer histograms are reproducible (two evaluations bit-identical) and their level-0 total is the row's mass."""
+    dtype, B, V, world = torch.bfloat16, 256, 151936, 8
+    vpr = V // world
+    full = _rand((B, V), dtype, 12, 1.0)
+    full[:128] *= 3.0                                       # peaked half / flat half
+    full[128:] *= 0.25
+    temps = torch.ones(B, device=DEV)
+    temps[::5] = 0.0
+    temps[1::5] = 0.6
+    top_ps = torch.ones(B, device=DEV)
+    top_ps[::2] = 0.9
+    top_ps[1::6] = 0.5
+    min_ps = torch.zeros(B, device=DEV)
+    min_ps[::3] = 0.02
+    ks = torch.full((B,), -1, dtype=torch.int64, device=DEV)
+    shards = [full[:, r * vpr:(r + 1) * vpr].contiguous() for r in range(world)]
+    row_max = torch.stack([s.amax(dim=1).float() for s in shards]).amax(dim=0)
+
+    def floor_of():
+        h0 = sum(H.shard_key_hist(s, row_max, temps, None) for s in shards)
+        state, prefix = H.nucleus_pick(h0, 0, top_ps, min_ps, temps, row_max, dtype)
+        h1 = sum(H.shard_key_hist(s, row_max, temps, prefix) for s in shards)
+        return h0, H.nucleus_pick(h1, 1, top_ps, min_ps, temps, row_max, dtype, state, prefix)
+
+    h0, floor = floor_of()
+    h0b, floor_b = floor_of()
+    assert torch.equal(h0, h0b) and torch.equal(floor, floor_b)
+    live = temps > 0
+    z = ((full[live].double() - row_max[live].double()[:, None]) / temps[live].double()[:, None]).exp().sum(1)
+    torch.testing.assert_close(h0[live].sum(1).double() / 2.0 ** 40, z, rtol=2e-5, atol=0)
+    plain = live & (top_ps >= 1) & (min_ps <= 0)
+    assert bool((floor[plain] == float("-inf")).all()) and bool((floor[~live] == float("-inf")).all())
+    _, mask = H.sample(full, temps, ks, top_ps, min_ps, seed=1, offset=1, return_mask=True)
+    mine = full.float() >= floor[:, None]
+    bad = ((mine != mask.bool()) & live[:, None]).sum(1)
+    assert int(bad.sum()) == 0, (bad.nonzero().flatten().tolist()[:8], int(bad.max()))
