@@ -96,6 +96,17 @@ __device__ __forceinline__ void lgkm_wait8(u32x2 (&lo)[4], u32x2 (&hi)[4]) {
                : "n"(N));
 }
 
+// max / sum across the two half-waves that share a query row (lane r and lane r + 32): one v_permlane32_swap (a VALU
+// instruction) instead of a ds_bpermute, whose compiler-inserted lgkmcnt(0) would also wait for every hand-counted
+// fragment read in flight
+__device__ __forceinline__ void half_swap(float x, float &lo, float &hi) {
+  // as inline assembly: with the builtin and the same value in both operands hipcc (ROCm 7.2) treats the two results as
+  // one value (ISA: `v_permlane32_swap v178, v0; v_add_f32 v0, v178, v178` for lo + hi).  `s_nop 1`: a VALU write of
+  // an operand right in front of v_permlane* needs wait states the compiler does not insert inside a statement.
+  lo = x;
+  hi = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+}
 // Round 2 (profiles/r02_prefill_kernel.md): the softmax arithmetic is scalar f32 (v_fma_f32 / v_exp_f32 / v_add_f32;
 // the packed v_pk_* forms cost more issue cycles beside MFMAs than the two ops they replace, and this file is built
 // with -fno-slp-vectorize so that the compiler does not pair them either), and a full tile's DMA source addresses
@@ -345,7 +356,13 @@ __global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams 
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kt][i]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if constexpr (PIPE) {   // (no LDS operation here: a ds_bpermute's lgkmcnt(0) would drain the V^T reads meant to land under the exponentials)
+      float lo, hi;
+      half_swap(mx, lo, hi);
+      mx = fmaxf(lo, hi);
+    } else {
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    }
     const float m_new = fmaxf(m_run, mx * scale_log2);  // scale > 0: max commutes with the scaling
     // rescale_thr = 0: rescale whenever some row's maximum moved.  > 0 (log2 units): only when one moved by more than
     // that — the stale maximum then leaves probabilities of up to 2^thr in P (fp32 sums, 16-bit P with the same
@@ -562,17 +579,6 @@ __device__ __forceinline__ void mfma_qk_kk_fence(f32x16 &d, f32x16 &f0, f32x16 &
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%3:%4], a[%5:%6], %0" : "+v"(d), "+v"(f0), "+v"(f1) : "i"(KLO), "i"(KLO + 3), "i"(QLO), "i"(QLO + 3));
   else
     asm volatile("v_mfma_f32_32x32x16_f16 %0, a[%3:%4], a[%5:%6], %0" : "+v"(d), "+v"(f0), "+v"(f1) : "i"(KLO), "i"(KLO + 3), "i"(QLO), "i"(QLO + 3));
-}
-// max / sum across the two half-waves that share a query row (lane r and lane r + 32): one v_permlane32_swap (a VALU
-// instruction) instead of a ds_bpermute, whose compiler-inserted lgkmcnt(0) would also wait for every hand-counted
-// fragment read in flight
-__device__ __forceinline__ void half_swap(float x, float &lo, float &hi) {
-  // as inline assembly: with the builtin and the same value in both operands hipcc (ROCm 7.2) treats the two results as
-  // one value (ISA: `v_permlane32_swap v178, v0; v_add_f32 v0, v178, v178` for lo + hi).  `s_nop 1`: a VALU write of
-  // an operand right in front of v_permlane* needs wait states the compiler does not insert inside a statement.
-  lo = x;
-  hi = x;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
 }
 template <int QLO, typename P>
 __device__ __forceinline__ void q_load(const P *ptr) {
