@@ -967,7 +967,7 @@ int mv_prefill_mfma_launch(const PrefillParams &p, int dtype, int variant, hipSt
   const int ablate64 = (no_dma ? 1 : 0) | (((variant >> 8) & 3) << 1);   // bench ablations of the 64-rows-per-wave kernel
   const float thr_pick = 6.0f + 2.0f * (float)((variant >> 6) & 3);   // bench switch: rescale threshold 6 / 8 / 10 / 12
   variant &= 7;
-  if (variant == 5) {   // bench switch (for now): 64 query rows per wave, one wave per SIMD
+  if (variant == 5) {   // bench switch: 64 query rows per wave, one wave per SIMD (profiles/r03_prefill_kernel.md)
     const int qblocks = (p.max_seqlen_q + 255) / 256;
     if (qblocks == 0 || p.n_seqs == 0) return MV_OK;
     const float thr64 = no_defer ? 0.0f : thr_pick;

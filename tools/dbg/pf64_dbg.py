@@ -5,14 +5,14 @@ import torch
 from minivllm_amd import hip_ops as H
 
 dev = torch.device("cuda", 0)
-for (S, hq, hkv) in ((257, 8, 1), (256, 2, 1), (512, 2, 1), (64, 1, 1), (128, 1, 1)):
+for (S, hq, hkv) in ((257, 8, 1), (256, 2, 1), (512, 2, 1), (64, 1, 1), (128, 1, 1), (1000, 4, 2), (4096, 2, 1)):
     g = torch.Generator().manual_seed(0)
     q = torch.randn(S, hq, 128, generator=g).bfloat16().to(dev)
     k = torch.randn(S, hkv, 128, generator=g).bfloat16().to(dev)
     v = torch.randn(S, hkv, 128, generator=g).bfloat16().to(dev)
     cu = torch.tensor([0, S], dtype=torch.int32, device=dev)
     a = H.prefill_varlen(q, k, v, cu, cu, S, S, 128 ** -0.5, flags=2 << 4).float()
-    for var in (5, 5 + (4 << 8), 5 + (8 << 8), 5 + (12 << 8)):
+    for var in (5,):
         b = H.prefill_varlen(q, k, v, cu, cu, S, S, 128 ** -0.5, flags=var << 4).float()
         err = (a - b).abs()
         print("variant", var, end=": ")
