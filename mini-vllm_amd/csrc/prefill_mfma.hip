@@ -488,20 +488,39 @@ __global__ void __launch_bounds__(NW * 64, 2) prefill_mfma_kernel(PrefillParams 
     if (t + 1 < n_tiles) tile(t + 1, std::integral_constant<int, 1>{});
   }
 
-  // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (r,h) owns d = 32dt + 8c + 4h + {0..3}
+  // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (r,h) owns d = 32dt + 8c + 4h + {0..3} of row r: sixteen 8-byte
+  //      pieces, each at another place of a 256-byte output row.  Stored like that (round 1-2) a wave instruction
+  //      wrote 32 partial lines at a stride of n_heads x 256 B (a power of two for 16 heads: the same channels over and
+  //      over): 5 % of the kernel at 4 x 4096, 9 % at 16 x 1024 (28/4), 30 % at 16 x 1024 (16/8) and 33 % at 64 x 256
+  //      (timing ablation, profiles/r03_prefill_kernel.md).  Now the wave's 32 x 128 tile goes through its own 8 KiB of
+  //      the (no longer needed) K|V buffers — 16-byte chunks XOR-swizzled by row so that both the 8-byte writes and the
+  //      16-byte reads spread over the banks — and leaves as whole rows: one instruction = four contiguous 256-B rows.
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (q_ok) {
-    T *op = (T *)p.out + ((int64_t)(q0 + qidx) * p.n_heads + head) * D;
+  // (every wave passed the barrier that ends the last tile: nobody reads the K|V buffers any more; a wave then only
+  //  touches its own 8 KiB, so no further barrier)
+  char *stage = smem + wave * (32 * ROW_BYTES);
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
+  for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        u32x2 w;
-        w[0] = pack2<Tag>(oacc[dt][4 * c + 0] * inv, oacc[dt][4 * c + 1] * inv);
-        w[1] = pack2<Tag>(oacc[dt][4 * c + 2] * inv, oacc[dt][4 * c + 3] * inv);
-        *reinterpret_cast<u32x2 *>(op + 32 * dt + 8 * c + 4 * h) = w;
+    for (int c = 0; c < 4; ++c) {
+      u32x2 w;
+      w[0] = pack2<Tag>(oacc[dt][4 * c + 0] * inv, oacc[dt][4 * c + 1] * inv);
+      w[1] = pack2<Tag>(oacc[dt][4 * c + 2] * inv, oacc[dt][4 * c + 3] * inv);
+      *reinterpret_cast<u32x2 *>(stage + r * ROW_BYTES + (((4 * dt + c) ^ (r & 15)) << 4) + 8 * h) = w;
+    }
+  {
+    const int rr = lane >> 4, cc = lane & 15;   // four rows per instruction, sixteen 16-byte chunks per row
+    const int row0 = qb * BM + wave * 32;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = 4 * it + rr;
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + row * ROW_BYTES + ((cc ^ (row & 15)) << 4));
+      if (row0 + row < sq && !(rescale_thr <= -2.f && lane != 0)) {   // (thr <= -2: bench ablation, timing only)
+        T *op = (T *)p.out + ((int64_t)(q0 + row0 + row) * p.n_heads + head) * D;
+        *reinterpret_cast<u32x4 *>(op + 8 * cc) = v;
       }
+    }
   }
 }
 
@@ -962,6 +981,7 @@ int mv_prefill_mfma_launch(const PrefillParams &p, int dtype, int variant, hipSt
   // blocks still fill the chip evenly; short prompts keep 4 waves x 2 workgroups per CU (measured per shape,
   // profiles/r02_prefill_kernel.md).  variant (bench switch, flags >> 4): 1 = force 4 waves, 2 = force 8
   // round 3: variants 3 / 4 = the round-2 loop (compiler-placed LDS reads) with 4 / 8 waves, for comparison
+  const int variant_in = variant;
   const bool no_defer = (variant & 8) != 0;   // bench switch: rescale on every tile whose maximum moved
   const bool no_dma = (variant & 16) != 0;    // bench ablation: K/V tiles are not refreshed (results are garbage)
   const int ablate64 = (no_dma ? 1 : 0) | (((variant >> 8) & 3) << 1);   // bench ablations of the 64-rows-per-wave kernel
@@ -985,7 +1005,8 @@ int mv_prefill_mfma_launch(const PrefillParams &p, int dtype, int variant, hipSt
   const bool pipe = variant != 3 && variant != 4;
   // rescale threshold (log2 units): the O accumulator is rescaled only when a row maximum grows by more than a factor of
   // 2^6 (+5.5 % at 4 x 4096; P then holds values up to 64, well inside bf16 / f16 range; same relative rounding)
-  const float thr = no_dma ? -1.0f : ((pipe && !no_defer) ? thr_pick : 0.0f);
+  // (bench ablations, timing only: bit 4 = no K/V refresh (thr -1), bit 10 = additionally no output stores (thr -2))
+  const float thr = ((variant_in >> 10) & 1) ? -2.0f : (no_dma ? -1.0f : ((pipe && !no_defer) ? thr_pick : 0.0f));
   const int nw = (variant == 1 || variant == 3) ? 4 : ((variant == 2 || variant == 4) ? 8 : (p.max_seqlen_q >= 2048 ? 8 : 4));
   const int bm = nw * 32;
   const int q_blocks = (p.max_seqlen_q + bm - 1) / bm;
