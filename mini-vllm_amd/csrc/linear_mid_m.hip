@@ -349,7 +349,7 @@ __global__ void __launch_bounds__((WM * WN + NLX + NLW) * 64) linear_mid_m_kerne
       for (int b = 0; b < TM; ++b) {
         const int m = m0 + (wm * TM + b) * 16 + r16;
         const int n = n0 + (wn * TN + a) * 16 + g * 4;
-        if (m < p.M && n < p.N) {
+        if (m < p.M && n < p.N && !((p.ablate & 8) && threadIdx.x != 0)) {   // (ablate: bench switch, timing only)
           if constexpr (EPI == EPI_PARTIAL) {
             float *dst = (float *)p.out + ((int64_t)blockIdx.y * p.M + m) * p.out_stride + n;
             *(f32x4 *)dst = acc[a][b];
@@ -531,7 +531,7 @@ extern "C" int mv_linear_mid_m(const void *x, int64_t x_stride, const void *w_pa
   if (bias && (((uintptr_t)bias) & 7u)) return MV_E_ALIGN;
   int flags = cfg / 100;          // bench only: +100 the DMA ring without the arithmetic (out untouched), +200 K rotation,
   cfg %= 100;                     // +400 no x DMA, +800 no W DMA (results are garbage: timing ablations)
-  if (cfg < 0 || cfg >= kNumCfgs || flags > 31) return MV_E_RANGE;   // +1600: clock stamps into `bias` (bench only)
+  if (cfg < 0 || cfg >= kNumCfgs || flags > 63) return MV_E_RANGE;   // +1600: clock stamps into `bias`; +3200: no output stores (bench only)
   if (cfg == 0) cfg = auto_cfg(m, n, k, false);
   MidParams p{x, w_packed, bias, out, x_stride, out_stride, m, n, k, 0, 0, 0, (flags & 2) ? 1 : 0, flags >> 2};
   if ((flags & 16) && !bias) return MV_E_NULLPTR;
