@@ -236,7 +236,7 @@ class InferenceExecutor:
                 else:
                     self._drop_speculation()
                     ids, pos = self._ship_decode(inp)
-                    mode = self._tp_mode(sequences)
+                    mode = self._tp_mode(sequences, decode=True)
                     logits = self.model.compute_logits(self.model(ids, pos), gather=mode == "gather")
                     tokens = self._sample_tokens(logits, sequences, mode)
             self._check_peer_waits(eager)
@@ -316,13 +316,16 @@ class InferenceExecutor:
     def _tp_greedy(self, sequences) -> bool:
         return self.tp_size > 1 and self.sampler is not None and all(s.temperature == 0 for s in sequences)
 
-    def _tp_mode(self, sequences) -> str:
+    def _tp_mode(self, sequences, decode: bool = False) -> str:
         """How a tensor-parallel batch gets its tokens: 'greedy' (per-rank argmax merge), 'cand' (per-rank top-64
         candidates: every row greedy or with 1 <= top_k <= 64, 16-bit logits), 'mass' (two-stage draw: every row
         greedy or sampled from the whole vocabulary — top_k off, top_p = 1, min_p = 0, the default SamplingParams) or
         'nuc' (top_k off everywhere, nucleus / min-p rows present: cross-rank floor, then the two-stage draw) or
         'gather' (all-gather of the [B, V/tp] logits: everything else, i.e. rows with 64 < top_k < vocab).
-        TP = 1: 'gather' (the plain sampler on the full row)."""
+        TP = 1: 'gather' (the plain sampler on the full row).  ``decode``: the batch is a decode step that may replay a
+        graph -- a 'nuc' batch whose graph family cannot exist (backend not capturable, or its capture failed) while
+        the gathered-logits family does is a 'gather' batch: a replayed gather beats an eager step with three extra
+        backend all-reduces.  The eager path, ``compute_logits(gather=...)`` and ``_replay_graph`` all ask here."""
         if self.tp_size == 1 or self.sampler is None:
             return "gather"
         if all(s.temperature == 0 for s in sequences):
@@ -337,8 +340,16 @@ class InferenceExecutor:
             return "mass"       # the default SamplingParams: the whole vocabulary, an exact two-stage draw
         if self.dtype in (torch.bfloat16, torch.float16) and vocab <= 1 << 24 and self.tp_size <= 16 and all(
                 s.temperature == 0 or s.top_k <= 0 or s.top_k >= vocab for s in sequences):
+            if decode and not self._nuc_family_usable():
+                return "gather"
             return "nuc"        # top_k off, some rows with top_p < 1 / min_p > 0: the ranks find the floor together
         return "gather"
+
+    def _nuc_family_usable(self) -> bool:
+        """False when a decode step in 'nuc' mode would run eagerly although a gathered-logits graph could serve it."""
+        if self.enforce_eager or self.nuc_graphs or self._nuc_capture == "lazy":
+            return True
+        return not (self.graphs or self._general_capture == "lazy")
 
     def _cand_tokens(self, logits_local, t, k, p, m):
         """'cand' mode, eager: the sampler (one Philox step, like any other batch) on the gathered candidates."""
@@ -406,7 +417,7 @@ class InferenceExecutor:
     def _graph_family(self, sequences, capture: bool = False):
         """-> (mode, graphs of the family this batch decodes with).  The candidate family and (under TP) the
         gathered-logits family are captured on first use."""
-        mode = self._tp_mode(sequences)
+        mode = self._tp_mode(sequences, decode=True)
         if mode == "greedy" and self.greedy_graphs:
             return "greedy", self.greedy_graphs
         if mode == "cand" and self._cand_capture != "no":
@@ -423,7 +434,9 @@ class InferenceExecutor:
                 self._drop_speculation()
                 torch.cuda.synchronize(self.device)
                 self._capture_nuc()
-            # (no graphs: the step runs eagerly in 'nuc' mode -- _graph_bucket finds no bucket in an empty family)
+                if not self._nuc_family_usable():    # the capture just failed: these batches replay the gather graphs
+                    return self._graph_family(sequences, capture)
+            # (no graphs at all: the step runs eagerly in 'nuc' mode -- _graph_bucket finds no bucket in an empty family)
             return "nuc", self.nuc_graphs
         if capture and self._general_capture == "lazy":
             self._drop_speculation()

@@ -3,11 +3,16 @@ postprocess until every request has finished.
 
 Tensor parallelism is SPMD.  With ``tensor_parallel_size > 1`` either
   * the process was launched by ``torch.distributed.run`` (RANK/WORLD_SIZE set): every rank builds
-    its own engine and calls ``generate`` with the same arguments, or
-  * rank 0 spawns the other ranks (one process per GPU, like the reference); each ``generate`` call
-    is broadcast once over the host control group and then runs identically everywhere.
+    its own engine and makes the same ``add_request`` / ``step`` / ``generate`` calls, or
+  * rank 0 spawns the other ranks (one process per GPU, like the reference) and every PUBLIC call of the
+    driver -- ``add_request``, ``step``, ``generate`` -- is relayed once over the host control group (gloo,
+    one small object per call, never inside a graph) and then runs identically everywhere.  This is the
+    reference's dispatch seam, ``ModelRunner.call("run", seqs, is_prefill)`` broadcast to the workers
+    (model_runner.py:173-198) under its ``add_request`` / ``step`` loop (llm_engine.py:171-251), with one
+    difference: what crosses the process boundary is the CALL, not the pickled batch -- every rank keeps
+    its own scheduler.
 Scheduling, block allocation and sampling (Philox keyed by seed/step/row) are deterministic, so
-all ranks stay in lock-step without any per-step control traffic."""
+all ranks stay in lock-step; ``generate`` needs one relay for the whole request list, not one per step."""
 from __future__ import annotations
 
 import atexit
@@ -31,23 +36,27 @@ __all__ = ["LLMEngine"]
 
 def _worker_main(config: Config, rank: int) -> None:
     os.environ["LOCAL_RANK"] = str(rank)
-    engine = LLMEngine(config, _rank=rank)
+    serve_worker(LLMEngine(config, _rank=rank), rank)
+
+
+def serve_worker(engine: "LLMEngine", rank: int) -> None:
+    """Loop of a spawned tensor-parallel worker (reference: ``ModelRunner._worker_loop``, model_runner.py:124-158):
+    wait for the driver's next relayed call, make it on this rank's engine, until "exit"."""
     dm = engine.model_runner.distributed_manager
     while True:
         cmd = dm.broadcast_data(None, src=0)
         if cmd[0] == "exit":
             break
-        if cmd[0] == "generate":
-            try:
-                engine._generate_local(cmd[1], cmd[2], use_tqdm=False)
-            except Exception:
-                # the driver validated the request before telling us, so this is a real fault: say so and leave
-                # with a non-zero code (the driver sees the dead worker and stops using the collective group)
-                logger.exception("tensor-parallel worker %d failed inside generate()", rank)
-                try:
-                    engine.model_runner.exit()
-                finally:
-                    os._exit(1)
+        try:
+            engine._serve_relayed(cmd)
+        except Exception:
+            # the driver validated the request before telling us, so this is a real fault: say so and leave
+            # with a non-zero code (the driver sees the dead worker and stops using the collective group)
+            # NO collective clean-up on the way out (ModelRunner.exit ends in a barrier + destroy_process_group that the
+            # other ranks are not in: the worker would sit there, alive, and the driver could not tell)
+            logger.exception("tensor-parallel worker %d failed inside %s()", rank, cmd[0])
+            logging.shutdown()
+            os._exit(1)
     engine.model_runner.exit()
 
 
@@ -133,16 +142,49 @@ class LLMEngine:
             raise ValueError(f"prompt of {len(prompt)} tokens exceeds what can be prefilled (max_model_len, KV pool; max_num_batched_tokens without chunked prefill): {limit}")
         return prompt
 
+    # ------------------------------------------------------------------ tensor-parallel relay (spawned workers)
+    def _relay(self, *cmd) -> None:
+        """Driver of spawned workers: tell them to make the same call.  A worker that has died can never take part in
+        the collectives of the step again -- that is an exception HERE, before this rank walks into an all-reduce alone
+        (whose bounded wait would only give up after csrc/allreduce.hip's 20 s)."""
+        if not self._is_driver:
+            return
+        dead = [i + 1 for i, p in enumerate(self.ps) if not p.is_alive()]
+        if dead:
+            raise RuntimeError(f"tensor-parallel worker process(es) {dead} have died (exit codes "
+                               f"{[self.ps[i - 1].exitcode for i in dead]}): this engine cannot serve any more")
+        self.model_runner.distributed_manager.broadcast_data(cmd, src=0)
+
+    def _serve_relayed(self, cmd) -> None:
+        """Worker side of ``_relay``: the same call on this rank's engine."""
+        op = cmd[0]
+        if op == "generate":
+            self._generate_local(cmd[1], cmd[2], use_tqdm=False)
+        elif op == "add_request":
+            self._add_request_local(cmd[1], cmd[2])
+        elif op == "step":
+            self._step_local()
+        else:
+            raise ValueError(f"unknown relayed call {op!r}")
+
     def add_request(self, prompt: str | list[int], sampling_params: SamplingParams | None = None) -> int:
         if sampling_params is None:
             sampling_params = SamplingParams()
-        prompt = self._validate_prompt(prompt)
+        prompt = self._validate_prompt(prompt)        # (tokenized on the driver: the workers get token ids)
+        self._relay("add_request", prompt, sampling_params)
+        return self._add_request_local(prompt, sampling_params)
+
+    def _add_request_local(self, prompt: list[int], sampling_params: SamplingParams) -> int:
         seq = Sequence(prompt, sampling_params, block_size=self.config.kvcache_block_size)
         self.scheduler.add(seq)
         return seq.seq_id
 
     def step(self):
         """-> ([(seq_id, completion_token_ids) for finished], +prefill tokens | -decode seqs)."""
+        self._relay("step")
+        return self._step_local()
+
+    def _step_local(self):
         sequences, is_prefill = self.scheduler.schedule()
         ex = getattr(self.model_runner, "inference_executor", None)
         if ex is not None:  # hint: with nothing waiting, the next step is a decode of (at most) this batch
@@ -166,10 +208,7 @@ class LLMEngine:
         if isinstance(sampling_params, list) and len(sampling_params) != len(prompts):
             raise ValueError("Length of sampling_params list must match prompts")
         prompts = [self._validate_prompt(p) for p in prompts]
-        if self._is_driver:
-            if any(not p.is_alive() for p in self.ps):
-                raise RuntimeError("a tensor-parallel worker process has died: this engine cannot serve any more")
-            self.model_runner.distributed_manager.broadcast_data(("generate", prompts, sampling_params), src=0)
+        self._relay("generate", prompts, sampling_params)
         return self._generate_local(prompts, sampling_params, use_tqdm)
 
     def _generate_local(self, prompts, sampling_params, use_tqdm: bool):
@@ -186,12 +225,12 @@ class LLMEngine:
             from tqdm.auto import tqdm
 
             pbar = tqdm(total=len(prompts), desc="Generating", dynamic_ncols=True)
-        ids = [self.add_request(p, sp) for p, sp in zip(prompts, sp_list)]
+        ids = [self._add_request_local(p, sp) for p, sp in zip(prompts, sp_list)]   # (validated by generate())
         outputs: dict[int, list[int]] = {}
         prefill_tps = decode_tps = 0.0
         while not self.is_finished():
             t0 = perf_counter()
-            finished, num_tokens = self.step()
+            finished, num_tokens = self._step_local()
             dt = perf_counter() - t0
             if num_tokens > 0:
                 prefill_tps = num_tokens / dt

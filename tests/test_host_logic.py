@@ -426,3 +426,41 @@ def test_warmup_runs_when_the_token_budget_is_below_half_the_model_length():
     assert InferenceExecutor.warmup_sequences(16384, 256, 40960) == 1     # chunked prefill as intended: was 0
     assert InferenceExecutor.warmup_sequences(16384, 256, 4096) == 2      # the reference's count where it is >= 1
     assert InferenceExecutor.warmup_sequences(16384, 1, 4096) == 1
+
+
+def test_nucleus_batches_fall_back_to_the_gather_graphs_when_their_own_family_cannot_exist():
+    """Tensor parallel, a batch with top-p rows and top_k off ('nuc' mode).  Its graph family holds backend
+    collectives and is captured lazily, only where the peer-to-peer all-reduce is up.  On an RCCL-only run (or after
+    a failed capture) the family stays empty while the gathered-logits graphs exist: such a batch must replay THOSE,
+    not drop to an eager step.  The eager path and the replay ask the same helper, so they agree."""
+    import torch
+
+    from minivllm_amd.engine.inference_executor import InferenceExecutor
+
+    ex = object.__new__(InferenceExecutor)
+    ex.tp_size, ex.sampler, ex.dtype, ex.enforce_eager = 2, object(), torch.bfloat16, False
+    ex.config = SimpleNamespace(hf_config=SimpleNamespace(vocab_size=151936))
+    ex.greedy_graphs, ex.cand_graphs, ex.mass_graphs, ex.nuc_graphs = {8: "g"}, {}, {}, {}
+    ex.graphs, ex.graph_bs = {8: "gather-graph"}, [8]
+    ex._general_capture, ex._nuc_capture, ex._cand_capture, ex._mass_capture = "done", "no", "no", "no"
+    sp = SamplingParams(temperature=0.8, top_p=0.9, max_tokens=4)
+    seqs = [Sequence([1, 2, 3], sp, block_size=64) for _ in range(3)]
+    assert ex._tp_mode(seqs) == "nuc"                          # prefill / no graph in play: the cross-rank floor
+    assert ex._tp_mode(seqs, decode=True) == "gather"
+    assert ex._graph_family(seqs) == ("gather", ex.graphs)
+    assert ex._graph_bucket(seqs) == 8                         # was None: the step decoded eagerly
+    # the family exists (or can still be captured): 'nuc' stays
+    ex.nuc_graphs = {8: "nuc-graph"}
+    assert ex._graph_family(seqs) == ("nuc", ex.nuc_graphs) and ex._tp_mode(seqs, decode=True) == "nuc"
+    ex.nuc_graphs, ex._nuc_capture = {}, "lazy"
+    assert ex._tp_mode(seqs, decode=True) == "nuc"
+    # no gather graphs either (gloo ranks: nothing with a backend collective is captured): eager 'nuc', as before
+    ex._nuc_capture, ex.graphs, ex._general_capture = "no", {}, "no"
+    assert ex._tp_mode(seqs, decode=True) == "nuc" and ex._graph_bucket(seqs) is None
+    # enforce_eager never changes the mode
+    ex.enforce_eager, ex.graphs = True, {8: "x"}
+    assert ex._tp_mode(seqs, decode=True) == "nuc"
+    # 'mass' batches (default SamplingParams) without their family already took the gather graphs
+    ex.enforce_eager = False
+    mass = [Sequence([1, 2, 3], SamplingParams(max_tokens=4), block_size=64)]
+    assert ex._graph_family(mass) == ("gather", ex.graphs)

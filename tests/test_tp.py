@@ -434,15 +434,9 @@ def test_custom_all_reduce_matches_backend(tmp_path, world):
 
 
 # ---------------------------------------------------------------------------------- GPU, LLM(tensor_parallel_size=2)
-@pytest.mark.gpu
-def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
-    """The user path: ``LLM(Config(dir, tensor_parallel_size=2))`` from ONE process spawns rank 1, both ranks
-    run the same scheduler (SPMD), requests travel over the control group; greedy output equals TP=1.
-    Both ranks share the box's single GPU (gloo for the collectives, the peer-to-peer kernel for the bf16
-    all-reduces), so this is a functional test of the multi-process flow, not of xGMI."""
+def _tiny_qwen3_checkpoint(golden_dir, tmp_path):
+    """The golden tiny Qwen3 as a safetensors checkpoint directory + its prompts."""
     from safetensors.torch import save_file
-
-    from minivllm_amd import LLM, Config, SamplingParams
 
     z = np.load(os.path.join(golden_dir, "e2e_qwen3.npz"))
     d = tmp_path / "ckpt"
@@ -455,6 +449,52 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
     prompts, o = [], 0
     for n in lens:
         prompts.append(flat[o:o + n]); o += n
+    return str(d), prompts
+
+
+@pytest.mark.gpu
+def test_spawned_tp2_add_request_and_step_equal_generate(golden_dir, tmp_path, monkeypatch):
+    """The reference's public loop -- ``add_request`` then ``step`` until finished (llm_engine.py:171-251) -- on the
+    DRIVER of a spawned TP=2 engine: every call is relayed to the worker (reference: model_runner.py:173-198
+    broadcasts each "run"), so the ranks enter every all-reduce together and the tokens equal ``generate()``'s on the
+    same engine.  Before round 4 only ``generate`` crossed the process boundary: a bare ``step()`` ran on rank 0
+    alone and sat in the peer-to-peer all-reduce until its 20 s bounded wait gave up.  bf16, hipGraph decode (the
+    all-greedy family: no backend collective inside), prompts shorter than a block so that the second pass has no
+    prefix-cache hits and computes exactly what the first did."""
+    from minivllm_amd import LLM, Config, SamplingParams
+
+    d, prompts = _tiny_qwen3_checkpoint(golden_dir, tmp_path)
+    prompts = [p[:50] for p in prompts]
+    monkeypatch.setenv("MINIVLLM_TP_BACKEND", "gloo")
+    sp = SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True)
+    llm = LLM(Config(d, dtype="bfloat16", tensor_parallel_size=2, seed=3, max_model_len=512, max_num_batched_tokens=1024,
+                     max_num_seqs=8, num_kvcache_blocks=24, enforce_eager=False))
+    try:
+        assert llm._is_driver and len(llm.ps) == 1
+        ids = [llm.add_request(p, sp) for p in prompts]
+        done, steps = {}, 0
+        while not llm.is_finished():
+            finished, _ = llm.step()
+            done.update(finished)
+            steps += 1
+        assert steps == 12 and sorted(done) == sorted(ids)
+        stepped = [done[i] for i in ids]
+        assert all(len(t) == 12 for t in stepped)
+        assert [o["token_ids"] for o in llm.generate(prompts, sp, use_tqdm=False)] == stepped
+        assert all(p.is_alive() for p in llm.ps)
+    finally:
+        llm.exit()
+
+
+@pytest.mark.gpu
+def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
+    """The user path: ``LLM(Config(dir, tensor_parallel_size=2))`` from ONE process spawns rank 1, both ranks
+    run the same scheduler (SPMD), requests travel over the control group; greedy output equals TP=1.
+    Both ranks share the box's single GPU (gloo for the collectives, the peer-to-peer kernel for the bf16
+    all-reduces), so this is a functional test of the multi-process flow, not of xGMI."""
+    from minivllm_amd import LLM, Config, SamplingParams
+
+    d, prompts = _tiny_qwen3_checkpoint(golden_dir, tmp_path)
     sp = SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True)
     kw = dict(max_model_len=512, max_num_batched_tokens=1024, max_num_seqs=8, num_kvcache_blocks=24,
               enforce_eager=True)
@@ -467,7 +507,7 @@ def test_llm_spawned_tp2_generates_like_tp1(golden_dir, tmp_path, monkeypatch):
 
             modes = set()
             real_mode = ex._tp_mode
-            ex._tp_mode = lambda seqs: (modes.add(real_mode(seqs)), real_mode(seqs))[1]
+            ex._tp_mode = lambda seqs, **kw: (modes.add(real_mode(seqs, **kw)), real_mode(seqs, **kw))[1]
             out = [o_["token_ids"] for o_ in llm.generate(prompts, sp, use_tqdm=False)]
             run.last = dict(modes=modes, cand_graphs=bool(ex.cand_graphs), mass_graphs=bool(ex.mass_graphs),
                             nuc_graphs=bool(ex.nuc_graphs))
