@@ -462,6 +462,10 @@ class InferenceExecutor:
                     logger.warning("tensor-parallel backend %s is not capturable: decoding eagerly", dist.get_backend())
                     return
         self.graph_bs = graph_batch_sizes(min(max_batch_size, self.config.max_num_seqs))
+        only = os.environ.get("MV_GRAPH_BATCH_SIZES")
+        if only:   # diagnostic / bench knob: capture just these buckets (bench.py's secondary TP engines replay one)
+            keep = {int(v) for v in only.split(",") if v.strip()}
+            self.graph_bs = [b for b in self.graph_bs if b in keep] or self.graph_bs
         max_bs = self.graph_bs[-1]
         hidden = self.config.hf_config.hidden_size
         vocab = self.config.hf_config.vocab_size

@@ -29,3 +29,52 @@ def test_multi_gpu_bench_launches_itself_under_torch_distributed_run():
 def test_usable_cores_is_positive_and_bounded():
     n = bench.usable_cores()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_record_plan_carries_the_whole_metric_for_every_gpu_count():
+    """BASELINE.json: "decode tokens/sec/GPU + prefill tok/s, Qwen3-1.7B TP=1 & Qwen2-7B TP=1/2/4/8", config 5 =
+    Qwen2-72B TP=8.  Every `bench.py --gpus N` the driver may run must have a producer for its share: the headline
+    first, then (N=1) sampled decode + the three config-4 prefill shapes + Qwen2-7B; (N=2,4) Qwen2-7B at TP=N;
+    (N=8) the Qwen2-7B rejection the reference's head rule demands (qwen_base.py:95-104) and Qwen2-72B on an
+    HBM-sized KV pool with max_model_len=4096."""
+    for n in (1, 2, 4, 8):
+        plan = bench.record_plan(n)
+        assert plan[0] == dict(kind="decode", model="qwen3-1.7b", tp=n, batch=256, ctx=1024, sampling="greedy", headline=True)
+        assert all(p["tp"] == n for p in plan) and sum(bool(p.get("headline")) for p in plan) == 1
+    kinds = lambda n: [(p["kind"], p["model"], p.get("sampling") or (p.get("prompts"), p.get("prompt_len"))) for p in bench.record_plan(n)[1:]]
+    assert kinds(1) == [("decode", "qwen3-1.7b", "sampled"),
+                        ("prefill", "qwen3-1.7b", (16, 1024)), ("prefill", "qwen3-1.7b", (4, 4096)), ("prefill", "qwen3-1.7b", (64, 256)),
+                        ("decode", "qwen2-7b", "greedy"),
+                        ("prefill", "qwen2-7b", (16, 1024)), ("prefill", "qwen2-7b", (4, 4096)), ("prefill", "qwen2-7b", (64, 256))]
+    for n in (2, 4):
+        assert kinds(n) == [("decode", "qwen2-7b", "greedy"), ("prefill", "qwen2-7b", (16, 1024)), ("prefill", "qwen2-7b", (4, 4096))]
+    assert kinds(8) == [("rejected", "qwen2-7b", (None, None)), ("decode", "qwen2-72b", "greedy")]
+    big = bench.record_plan(8)[-1]
+    assert big["auto_kv"] and big["max_model_len"] == 4096 and (big["batch"], big["ctx"]) == (256, 1024)
+    # the divisibility rule itself, as the reference states it
+    assert [bench.tp_allowed("qwen2-7b", n) for n in (1, 2, 4, 8)] == [True, True, True, False]
+    assert all(bench.tp_allowed(m, 8) for m in ("qwen3-1.7b", "qwen2-72b"))
+
+
+def test_projection_plan_ingest_figures_for_the_headline_shapes():
+    """The second bound next to the HBM fraction of linear_mid_m_kernel: what the busiest CU takes in.  Qwen3-1.7B at 256
+    rows, the tuned tiles (tuned/mid_m_gfx950.json): 2.49 MB per CU and layer -> 34-38 us at 66-73 GB/s per CU."""
+    shapes = (("col", 4096, 2048), ("row", 2048, 2048), ("gated", 6144, 2048), ("row", 2048, 6144))
+    plans = [bench.projection_plan(kind, 256, n, k) for kind, n, k in shapes]
+    assert all(p is not None and p["workgroups"] > 0 for p in plans)
+    for p, (kind, n, k) in zip(plans, shapes):
+        bm, bn = p["tile"]
+        bno = bn // 2 if kind == "gated" else bn
+        wgs = -(-256 // bm) * -(-n // bno) * p["k_splits"]
+        assert p["workgroups"] == wgs
+        assert p["ingest_bytes_per_cu"] == -(-wgs // 256) * (bm + bn) * (k // p["k_splits"]) * 2
+        lo, hi = p["ingest_bound_us"]
+        assert lo < hi and abs(hi - p["ingest_bytes_per_cu"] / 66e3) < 0.01
+    total = sum(p["ingest_bytes_per_cu"] for p in plans)
+    assert 2.0e6 < total < 3.0e6
+
+
+def test_prefill_flops_formula():
+    # SURVEY 8(d) K2: 4 H D (Sq Sk - Sq (Sq - 1) / 2); S = 4096, H = 28, D = 128 -> 1.20e11 per sequence and layer
+    assert abs(bench.prefill_flops(28, 128, [4096]) / 1.20e11 - 1) < 0.01
+    assert bench.prefill_flops(16, 128, [1024] * 16) == 16 * 4 * 16 * 128 * (1024 * 1024 - 1024 * 1023 // 2)

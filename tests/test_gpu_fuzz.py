@@ -123,10 +123,11 @@ def test_prefill_mfma_random_shapes(H, seed):
     g = torch.Generator().manual_seed(seed)
     dtype = rng.choice([torch.bfloat16, torch.float16])
     hkv, grp = rng.choice([(8, 2), (4, 7), (1, 8), (2, 1), (4, 4)])
-    hq, D, bs = hkv * grp, 128, 64
+    paged = seed % 2 == 1
+    # every legal engine block size (Config: multiples of 64; reference config.py:178-185) for the paged-prefix form
+    hq, D, bs = hkv * grp, 128, ((64, 128, 256)[(seed // 2) % 3] if paged else 64)
     n = rng.randint(1, 4)
     lens = [rng.choice([1, 31, 32, 33, 63, 64, 65, 127, 129, 200, 257, rng.randint(1, 700), rng.randint(300, 1200)]) for _ in range(n)]
-    paged = seed % 2 == 1
     cached = [(rng.randint(0, (ln - 1) // bs) * bs if paged else 0) for ln in lens]
     T = sum(lens)
     q = torch.randn(T, hq, D, generator=g)
@@ -170,5 +171,5 @@ def test_prefill_mfma_random_shapes(H, seed):
     for variant in (1, 2, 5):                                  # 4 waves / 8 waves (hand-placed reads) / 64 rows per wave
         outs = [H.prefill_varlen(*args, flags=variant << 4, **kw) for _ in range(3)]
         torch.testing.assert_close(outs[0].float().cpu(), want, msg=lambda m: f"seed {seed} variant {variant} {dtype} "
-                                   f"heads {hq}/{hkv} lens {lens} cached {cached}: {m}", **tol)
+                                   f"heads {hq}/{hkv} lens {lens} cached {cached} block {bs}: {m}", **tol)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (seed, variant)
