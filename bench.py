@@ -348,6 +348,7 @@ def decode_roofline(engine, args, model=None):
     return roof, ar_probe
 
 
+@torch.inference_mode()
 def _graph_time_us(fn, launches: int, reps: int = 5) -> float:
     """Microseconds per launch of ``fn`` (which enqueues ``launches`` kernels on the current stream): captured into a
     hipGraph -- how the decode step itself runs them -- and replayed between one HIP event pair per replay (on the
