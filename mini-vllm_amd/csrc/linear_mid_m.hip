@@ -532,6 +532,11 @@ extern "C" int mv_linear_mid_m(const void *x, int64_t x_stride, const void *w_pa
   int flags = cfg / 100;          // bench only: +100 the DMA ring without the arithmetic (out untouched), +200 K rotation,
   cfg %= 100;                     // +400 no x DMA, +800 no W DMA (results are garbage: timing ablations)
   if (cfg < 0 || cfg >= kNumCfgs || flags > 63) return MV_E_RANGE;   // +1600: clock stamps into `bias`; +3200: no output stores (bench only)
+#ifndef MV_BENCH_ABLATE
+  // the timing ablations leave garbage (or nothing) in `out`, and the clock stamps write 16 bytes per workgroup into
+  // `bias`: they exist only in a bench build (make ABLATE=1), never behind the production entry point
+  if (flags) return MV_E_RANGE;
+#endif
   if (cfg == 0) cfg = auto_cfg(m, n, k, false);
   MidParams p{x, w_packed, bias, out, x_stride, out_stride, m, n, k, 0, 0, 0, (flags & 2) ? 1 : 0, flags >> 2};
   if ((flags & 16) && !bias) return MV_E_NULLPTR;

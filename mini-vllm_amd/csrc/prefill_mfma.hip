@@ -981,6 +981,11 @@ int mv_prefill_mfma_launch(const PrefillParams &p, int dtype, int variant, hipSt
   // blocks still fill the chip evenly; short prompts keep 4 waves x 2 workgroups per CU (measured per shape,
   // profiles/r02_prefill_kernel.md).  variant (bench switch, flags >> 4): 1 = force 4 waves, 2 = force 8
   // round 3: variants 3 / 4 = the round-2 loop (compiler-placed LDS reads) with 4 / 8 waves, for comparison
+#ifndef MV_BENCH_ABLATE
+  // timing ablations whose results are garbage (no K/V refresh, no output stores, the 64-row kernel's ablations) exist
+  // only in a bench build (make ABLATE=1); the variants that stay compute the same attention
+  if (variant & (16 | (3 << 8) | (1 << 10))) return MV_E_RANGE;
+#endif
   const int variant_in = variant;
   const bool no_defer = (variant & 8) != 0;   // bench switch: rescale on every tile whose maximum moved
   const bool no_dma = (variant & 16) != 0;    // bench ablation: K/V tiles are not refreshed (results are garbage)

@@ -953,6 +953,30 @@ def test_linear_mid_m_every_tile(H, dtype, m, n, k, bias):
     assert torch.equal(H.linear_mid_m(wide[:, 32:32 + k], wp, n, b, cfg=1), H.linear_mid_m(x, wp, n, b, cfg=1))
 
 
+def test_timing_ablation_switches_are_not_reachable_in_the_production_build(H):
+    """the bench-only switches of mv_linear_mid_m (cfg + 100 x flags: DMA ring only, no x / W DMA, clock
+    stamps INTO `bias`, no output stores) and of mv_prefill_varlen (no K/V refresh, no output stores) leave garbage or
+    write out of bounds.  They are compiled only with `make ABLATE=1`; the shipped library answers MV_E_RANGE."""
+    x = _randn(64, 256, dtype=torch.bfloat16, seed=1).to(DEV)
+    w = _randn(128, 256, dtype=torch.bfloat16, seed=2).to(DEV)
+    b = _randn(128, dtype=torch.bfloat16, seed=3).to(DEV)
+    wp = H.pack_weight(w)
+    good = H.linear_mid_m(x, wp, 128, b, cfg=4)
+    for flag in (100, 200, 400, 800, 1600, 3200):
+        with pytest.raises(H.MvHipError, match="range"):
+            H.linear_mid_m(x, wp, 128, b, cfg=4 + flag)
+    assert torch.equal(H.linear_mid_m(x, wp, 128, b, cfg=4), good)
+    q = _randn(70, 4, 128, dtype=torch.bfloat16, seed=4).to(DEV)
+    k = _randn(70, 2, 128, dtype=torch.bfloat16, seed=5).to(DEV)
+    v = _randn(70, 2, 128, dtype=torch.bfloat16, seed=6).to(DEV)
+    cu = torch.tensor([0, 70], dtype=torch.int32, device=DEV)
+    ok = H.prefill_varlen(q, k, v, cu, cu, 70, 70, 128 ** -0.5)
+    for variant in (16, 1 << 8, 2 << 8, 1 << 10, 5 | 16):
+        with pytest.raises(H.MvHipError, match="range"):
+            H.prefill_varlen(q, k, v, cu, cu, 70, 70, 128 ** -0.5, flags=variant << 4)
+    assert torch.equal(H.prefill_varlen(q, k, v, cu, cu, 70, 70, 128 ** -0.5), ok)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,inter,k", [(256, 6144, 2048), (128, 18944, 512), (40, 1008, 256), (256, 3696, 1024)])
 def test_gate_up_silu_mid_m(H, dtype, m, inter, k):
