@@ -706,6 +706,57 @@ def test_nucleus_floor_across_shards_is_the_full_row_keep_mask(H, dtype, world):
     assert torch.equal(masked, torch.where(full.float() >= floor[:, None], full, torch.full_like(full, float("-inf"))))
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_nucleus_floor_with_ties_at_the_edge(H, world):
+    """rows made of a few distinct values, so that the nucleus edge falls ON a tie group, with p just below
+    and just above the group boundaries -- the case where the cross-rank floor (budget = trunc(p * Z) on 2^-40 fixed-point
+    masses, `mv_nucleus_pick`) could part ways with `mv_sample` (fp32 masses) and with the reference's sort-based cut.
+    Pinned here: (1) the emulated ranks keep EXACTLY `mv_sample`'s set, at every p; (2) both keep the edge's tie group
+    WHOLE, where the reference (functional.py:137-191: sort, cumsum, shift by one) cuts it at whatever position its sort
+    leaves the equal values in -- so the reference's kept set is a subset that differs only inside that one group (the
+    documented, intended difference: DESIGN.md section 3); (3) an all-equal row keeps everything."""
+    dtype, vocab = torch.bfloat16, 256 * world
+    levels = [(4.0, 3), (2.5, 17), (1.0, 100)]                       # (value, count); the rest of the row is 0.0
+    row = torch.zeros(vocab)
+    perm = torch.randperm(vocab, generator=torch.Generator().manual_seed(7))   # tie groups scattered over all shards
+    o = 0
+    for val, cnt in levels:
+        row[perm[o:o + cnt]] = val
+        o += cnt
+    mass = [(v, c * torch.tensor(v).exp().item()) for v, c in levels] + [(0.0, float(vocab - o))]
+    z = sum(m for _, m in mass)
+    cum, ps = 0.0, []
+    for _, m in mass[:-1]:
+        cum += m
+        ps += [cum / z - 2e-3, cum / z + 2e-3]                       # just inside / just past every group boundary
+    ps += [0.02, 0.9999]
+    B = len(ps) + 1
+    full = row.repeat(B, 1)
+    full[-1] = 1.5                                                   # the all-equal row
+    full = full.to(dtype).to(DEV)
+    temps = torch.ones(B, device=DEV)
+    top_ps = torch.tensor(ps + [0.5], device=DEV)
+    min_ps = torch.zeros(B, device=DEV)
+    ks = torch.full((B,), -1, dtype=torch.int64, device=DEV)
+    shards, _, _, floor = _emulated_nucleus_floor(H, full, world, temps, top_ps, min_ps)
+    _, mask = H.sample(full, temps, ks, top_ps, min_ps, seed=1, offset=1, return_mask=True)
+    ref_keep = O.sampler_probs(full.float().cpu(), temps.cpu(), ks.cpu(), top_ps.cpu(), min_ps.cpu()) > 0
+    vals = full.float().cpu()
+    for b in range(B):
+        mine = (full[b].float() >= floor[b]).cpu()
+        assert torch.equal(mine, mask[b].bool().cpu()), (b, ps[b] if b < len(ps) else "flat", int(mine.sum()), int(mask[b].sum()))
+        edge = vals[b][mine].min()
+        assert torch.equal(mine, vals[b] >= edge)                    # whole tie groups, nothing else
+        ref = ref_keep[b]
+        assert bool((ref & ~mine).sum() == 0), b                     # the reference keeps nothing this build drops
+        assert vals[b][ref].min() == edge                            # ... and stops inside the same tie group
+        assert torch.equal(ref | (vals[b] == edge), mine)
+    assert mask[-1].all() and floor[-1].item() <= 1.5
+    # the expected group count at each constructed p: below a boundary the group that crosses it is the edge
+    kept_groups = [int((vals[b][(full[b].float() >= floor[b]).cpu()]).unique().numel()) for b in range(len(ps))]
+    assert kept_groups[:6] == [1, 2, 2, 3, 3, 4], kept_groups
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_nucleus_draw_across_shards_follows_the_filtered_softmax(H, world):
     """The whole gather-free nucleus sequence (floor -> masked shards -> local draws with statistics -> rank pick) with

@@ -1,7 +1,11 @@
 #!/bin/bash
-# round 3 profile artefacts: decode traces (1.7B, 7B, B=1), PMC passes (decode attention, mid-M projections, prefill kernel)
+# The profile artefacts of a round, in one GPU call: decode traces (1.7B, 7B, B=1: rocprofv3 --kernel-trace --stats),
+# PMC passes in runs of their own (decode attention FETCH/WRITE_SIZE, mid-M projections, prefill kernel MFMA-busy / wave
+# time), decode sweeps, the bench lines.  Usage on the GPU box:  bash tools/profiles_round.sh r04   -> gpurun_out/r04p/...;
+# the summaries to be judged are then copied into profiles/ (tracked) by hand with the round prefix.
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3p
+O=gpurun_out/${TAG}p
 mkdir -p $O
 csvof() { ls $1/*/run_$2.csv $1/run_$2.csv 2>/dev/null | head -1; }
 trace() { # name, bench args...
