@@ -199,6 +199,43 @@ int mv_decode_advance(int64_t *input_ids, const int64_t *tokens, int64_t *positi
                       int32_t *slot_mapping, int32_t *context_lens, int64_t *rng_offset,
                       int batch, void *stream);
 
+/* K12 — every decoder layer of a SMALL decode step (<= 16 rows) in ONE persistent launch: per layer, between grid
+ * barriers, residual add + RMSNorm + qkv projection | head norms + RoPE + K/V store + paged attention | split-KV combine |
+ * o_proj | residual add + RMSNorm + gate_up + SiluAndMul | down_proj — the op order of QwenDecoderLayer.forward /
+ * QwenAttention.forward / QwenMLP.forward (minivllm/models/qwen_base.py:281-298, :173-190, :232-236), replacing the six
+ * launches per layer of the multi-launch path bit for bit (same K slices, same summation order, same rounding points).
+ * The next projection's weights stream into LDS while a workgroup waits at a barrier.  One workgroup per CU; all must be
+ * resident (nothing else may hold CUs for long on the device while it runs).
+ *   layers_dev: DEVICE array of n_layers MvPersistLayer (pointers to the packed weights / norm weights / KV planes);
+ *   a:          HOST struct (copied into the launch); x_in [m, hidden] = the embedding output, res_in = NULL;
+ *   workspace:  mv_decode_layers_persistent_workspace_bytes(...) bytes, 256-byte aligned; on return (stream order) the last
+ *               layer's down_proj output is at workspace + out_h_offset and the residual at workspace + out_res_offset
+ *               ([m, hidden] contiguous): the caller runs the final norm + LM head on them;
+ *   status_dev: one uint32: != 0 after the launch = a bounded barrier wait gave up, the results are invalid;
+ *   flags:      bits 0-7 weight chunks (8 KiB) per streaming wave kept in flight across a barrier (0 = default 2, 0xff = none).
+ * MV_E_SHAPE for what this form does not take (more than 16 rows, head_dim != 128, more than 4 query heads per kv head,
+ * wide output tiles, TP shards ...): the caller then runs the multi-launch path. */
+typedef struct MvPersistLayer {
+  const void *ln1_w, *wqkv, *bqkv, *q_norm_w, *k_norm_w, *wo, *ln2_w, *wgu, *wdown;
+  void *k_cache, *v_cache;
+} MvPersistLayer;
+typedef struct MvPersistArgs {
+  int m, hidden, n_heads, n_kv_heads, head_dim, inter;
+  float eps, scale;
+  const void *x_in, *res_in;
+  int64_t x_in_stride, res_in_stride;
+  const int64_t *positions;
+  const int32_t *slot_mapping, *block_tables, *context_lens;
+  int64_t table_stride, num_blocks, max_pos;
+  int block_size, max_blocks;
+  const float *cos, *sin;
+  int64_t out_h_offset, out_res_offset;   /* filled in by the call */
+} MvPersistArgs;
+size_t mv_decode_layers_persistent_workspace_bytes(int m, int hidden, int n_heads, int n_kv_heads, int head_dim, int inter,
+                                                   int block_size, int max_blocks);
+int mv_decode_layers_persistent(const MvPersistLayer *layers_dev, int n_layers, MvPersistArgs *a, void *workspace,
+                                size_t ws_bytes, unsigned *status_dev, int dtype, int flags, void *stream);
+
 /* K9 — SiluAndMul: out[r, c] = silu(x[r, c]) * x[r, cols + c].
  * Replaces SiluAndMul.forward (minivllm/models/layers/activation.py:70-96). */
 int mv_silu_and_mul(const void *x, int64_t x_stride, void *out,

@@ -7,6 +7,10 @@
 #include "../../include/mvhip.h"
 
 #define MV_WAVE 64
+// explicit address spaces for accesses through pointers whose provenance the compiler cannot see (pointers read from
+// memory, pointers carried in structs): without them such accesses become flat_ instructions
+#define MV_AS1 __attribute__((address_space(1)))
+#define MV_AS3 __attribute__((address_space(3)))
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;

@@ -36,6 +36,64 @@ struct DecodeParams {
   const int32_t *slot_mapping = nullptr;
 };
 
+// ---- accesses to bytes that ANOTHER workgroup of the same launch wrote or will read (persistent decode kernel) -------
+// COH = false: plain accesses (one kernel per phase: the kernel boundary makes everything visible).  COH = true: the
+// fence-free hand-off of MI355X_MICROARCH.md "Valid forms", table row 1 — every store write-through (`sc1`: relaxed
+// agent-scope atomics of 4 / 8 bytes lower to global_store_dword[x2] ... sc1), every load an `sc1` load that bypasses this
+// CU's L1; the storing waves drain (s_waitcnt vmcnt(0)) and meet at a workgroup barrier before ONE lane signals, readers
+// load behind the poll and a workgroup barrier (decode_persistent.hip: grid_barrier).  Measured: tools/dbg/barrier_probe.hip.
+template <bool COH>
+__device__ __forceinline__ u32x4 ld16(const void *p) {
+  if constexpr (!COH) {
+    return *reinterpret_cast<const u32x4 *>(p);
+  } else {
+    uint64_t *q = (uint64_t *)p;
+    const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return u32x4{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+  }
+}
+template <bool COH>
+__device__ __forceinline__ void st16(void *p, const u32x4 &v) {
+  if constexpr (!COH) {
+    *reinterpret_cast<u32x4 *>(p) = v;
+  } else {
+    uint64_t *q = (uint64_t *)p;
+    __hip_atomic_store(q, (uint64_t)v[0] | ((uint64_t)v[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, (uint64_t)v[2] | ((uint64_t)v[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <bool COH>
+__device__ __forceinline__ void st8(void *p, const u32x2 &v) {
+  if constexpr (!COH) *reinterpret_cast<u32x2 *>(p) = v;
+  else __hip_atomic_store((uint64_t *)p, (uint64_t)v[0] | ((uint64_t)v[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COH>
+__device__ __forceinline__ float ldf(const float *p) {
+  if constexpr (!COH) return *p;
+  else return u2f(__hip_atomic_load((uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <bool COH>
+__device__ __forceinline__ void stf(float *p, float v) {
+  if constexpr (!COH) *p = v;
+  else __hip_atomic_store((uint32_t *)p, f2u(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COH>
+__device__ __forceinline__ f32x4 ldf4(const float *p) {
+  if constexpr (!COH) {
+    return *reinterpret_cast<const f32x4 *>(p);
+  } else {
+    const u32x4 r = ld16<true>(p);
+    return f32x4{u2f(r[0]), u2f(r[1]), u2f(r[2]), u2f(r[3])};
+  }
+}
+// a 2-byte element: there is no 16-bit atomic store; the write-through form is the instruction itself
+template <bool COH>
+__device__ __forceinline__ void st2(uint16_t *p, uint16_t v) {
+  if constexpr (!COH) *p = v;
+  else asm volatile("global_store_short %0, %1, off sc1" ::"v"(p), "v"((uint32_t)v) : "memory");
+}
+
 // one head row (D elements on LPT lanes, VEC per lane): optional RMSNorm over the row (result rounded to dtype) and
 // the NeoX rotation by (cs, sn) — rope_qk_store_kernel's arithmetic and rounding points, statement for statement
 template <typename Tag, int D>
@@ -52,7 +110,8 @@ __device__ __forceinline__ u32x4 norm_rope_row(const u32x4 &raw, const typename 
     for (int off = 1; off < LPT; off <<= 1) ss += __shfl_xor(ss, off, 64);
     const float rs = 1.0f / sqrtf(ss / (float)D + eps);
     float w[VEC];
-    unpack8<Tag>(*reinterpret_cast<const u32x4 *>(nw + sub * VEC), w);
+    const u32x4 wraw = *(const MV_AS1 u32x4 *)(nw + sub * VEC);
+    unpack8<Tag>(wraw, w);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) x[j] = elem<Tag>::ld(elem<Tag>::st(__fmul_rn(__fmul_rn(x[j], rs), w[j])));
   }

@@ -240,6 +240,7 @@ class InferenceExecutor:
                     logits = self.model.compute_logits(self.model(ids, pos), gather=mode == "gather")
                     tokens = self._sample_tokens(logits, sequences, mode)
             self._check_peer_waits(eager)
+            self._check_persistent_launch()
             self._update_metrics(sequences, prefill)
             self.inference_count += 1
             return logits, tokens
@@ -258,6 +259,16 @@ class InferenceExecutor:
             slot = ar.post_status()
             torch.cuda.current_stream().synchronize()
             ar.verify(slot)
+
+    def _check_persistent_launch(self) -> None:
+        """Small decode steps run every layer in one persistent launch whose grid barriers are bounded waits
+        (csrc/decode_persistent.hip): a wait that gave up means the step's activations are garbage.  The status word came
+        back with the step (glue/qwen.py copies it behind the launch); the tokens have been read, so it is current."""
+        fn = getattr(getattr(self.model, "model", None), "persistent_give_ups", None)
+        if fn is not None and fn():
+            raise RuntimeError("persistent decode launch: a grid-barrier wait gave up (workgroups not co-resident or a "
+                               "device fault); the results of this step are invalid.  MV_PERSISTENT=0 selects the "
+                               "multi-launch path")
 
     def _to_dev(self, t: torch.Tensor | None):
         return None if t is None else t.to(self.device, non_blocking=True)

@@ -97,6 +97,13 @@ ROPE_FOLD = os.environ.get("MV_ROPE_FOLD", "1") != "0"
 # (B = 1: 1.42 -> 1.38 ms, B = 16 ... 128: -1.2 ... -2 %); at B = 256 the work costs the attention kernel what the
 # separate launch cost (7.00 ms both ways), so larger steps keep mv_rope_qk_store
 ROPE_FOLD_MAX_ROWS = int(os.environ.get("MV_ROPE_FOLD_MAX", "128"))
+# decode steps of <= 16 rows: every decoder layer in ONE persistent launch (csrc/decode_persistent.hip), bit-identical to
+# the multi-launch path.  MV_PERSISTENT=0 keeps the launches; MV_PERSISTENT_PREFETCH = weight chunks per wave in flight
+# across a barrier (default 2, "none" = 0xff)
+PERSISTENT = os.environ.get("MV_PERSISTENT", "1") != "0"
+PERSISTENT_FLAGS = {"none": 0xff}.get(os.environ.get("MV_PERSISTENT_PREFETCH", ""), None)
+if PERSISTENT_FLAGS is None:
+    PERSISTENT_FLAGS = int(os.environ.get("MV_PERSISTENT_PREFETCH", "0") or 0)
 
 
 class QwenAttention(nn.Module):
@@ -267,8 +274,76 @@ class QwenModel(nn.Module):
         self.layers = nn.ModuleList(self.decoder_layer_cls(config) for _ in range(config.num_hidden_layers))
         self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
+    # ---- small decode steps: all layers in one persistent launch -----------------------------------------------------
+    def _persistent_state(self, x):
+        """Layer table + workspace + status word for mv_decode_layers_persistent, (re)built when the KV planes or the
+        packed weights moved; None when the model does not qualify (unpacked weights, tensor parallel, other dtypes)."""
+        layers = list(self.layers)
+        a0 = layers[0].self_attn
+        if (get_tensor_parallel_world_size() != 1 or x.dtype not in (torch.bfloat16, torch.float16) or a0.head_dim != 128
+                or any(lin.weight_packed is None for l in layers
+                       for lin in (l.self_attn.qkv_proj, l.self_attn.o_proj, l.mlp.gate_up_proj, l.mlp.down_proj))
+                or a0.o_proj.bias is not None or layers[0].mlp.down_proj.bias is not None):
+            return None
+        key = tuple((l.self_attn.attn.k_cache.data_ptr(), l.self_attn.qkv_proj.weight_packed.data_ptr()) for l in layers)
+        st = getattr(self, "_persist", None)
+        if st is None or st["key"] != key:
+            rows = []
+            for l in layers:
+                at, mlp = l.self_attn, l.mlp
+                rows.append(dict(ln1_w=l.input_layernorm.weight, wqkv=at.qkv_proj.weight_packed, bqkv=at.qkv_proj.bias,
+                                 q_norm_w=None if at.q_norm is None else at.q_norm.weight,
+                                 k_norm_w=None if at.k_norm is None else at.k_norm.weight, wo=at.o_proj.weight_packed,
+                                 ln2_w=l.post_attention_layernorm.weight, wgu=mlp.gate_up_proj.weight_packed,
+                                 wdown=mlp.down_proj.weight_packed, k_cache=at.attn.k_cache, v_cache=at.attn.v_cache))
+            st = self._persist = dict(
+                key=key, table=hip_ops.persist_layer_table(rows, x.device), keep=rows,
+                status=torch.zeros(4, dtype=torch.int32, device=x.device),
+                status_host=torch.zeros(4, dtype=torch.int32).pin_memory(), ws={})
+        return st
+
+    def _forward_persistent(self, hidden_states, positions):
+        """-> (h, residual) of the last layer, or None (the caller then runs the layers one launch at a time)."""
+        ctx = get_context()
+        t = hidden_states.shape[0] if hidden_states.dim() == 2 else 0
+        a0 = self.layers[0].self_attn
+        if (not PERSISTENT or not 0 < t <= hip_ops.PERSIST_MAX_ROWS or ctx.is_prefill or ctx.slot_mapping is None
+                or ctx.block_tables is None or ctx.context_lens is None or a0.attn.k_cache.numel() == 0
+                or ctx.block_tables.dim() != 2 or ctx.block_tables.shape[1] == 0):
+            return None
+        st = self._persistent_state(hidden_states)
+        if st is None or st.get("declined"):
+            return None
+        kc = a0.attn.k_cache
+        width = ctx.block_tables.shape[1]
+        ws = st["ws"].get((t, width))
+        if ws is None:
+            ws = st["ws"][(t, width)] = hip_ops.decode_layers_persistent_workspace(
+                t, hidden_states.shape[1], a0.num_heads, a0.num_kv_heads, a0.head_dim, self.layers[0].mlp.intermediate_size,
+                kc.shape[1], width, hidden_states.device)
+        cos, sin = a0.rotary_emb._tables(hidden_states.device, hidden_states.dtype)
+        got = hip_ops.decode_layers_persistent(
+            st["table"], len(self.layers), hidden_states, positions, ctx.slot_mapping, ctx.block_tables, ctx.context_lens,
+            cos, sin, kc, a0.num_heads, a0.num_kv_heads, a0.head_dim, self.layers[0].mlp.intermediate_size,
+            a0.rms_norm_eps, a0.attn.scale, ws, st["status"], PERSISTENT_FLAGS)
+        if got is None:
+            st["declined"] = True           # a shape the kernel does not take: do not ask again
+            return None
+        st["status_host"].copy_(st["status"], non_blocking=True)   # read by the executor once the step's tokens are back
+        return got
+
+    def persistent_give_ups(self) -> int:
+        """Bounded barrier waits of the persistent decode launch that gave up (0 = fine).  Valid once the stream work of the
+        step has completed (the executor asks after it has read the step's tokens)."""
+        st = getattr(self, "_persist", None)
+        return 0 if st is None else int(st["status_host"][0])
+
     def forward(self, input_ids, positions):
         hidden_states, residual, pending = self.embed_tokens(input_ids), None, False
+        fused = self._forward_persistent(hidden_states, positions)
+        if fused is not None:
+            hidden_states, _ = self.norm(fused[0], fused[1])
+            return hidden_states
         for layer in self.layers:
             hidden_states, residual = layer(positions, hidden_states, residual, pending)
             pending = layer.defers_reduce

@@ -103,6 +103,8 @@ _SIGNATURES = {
                                 c_int, c_int, c_void_p]),
     "mv_mask_below": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mv_topc_pick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mv_decode_layers_persistent_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mv_decode_layers_persistent": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -639,6 +641,64 @@ def linear_mid_m_partial(x, w_packed, n: int, splits: int, cfg: int = 0):
                                         x2.shape[0], n, k, int(splits), _dt(x), int(cfg), _stream()),
            "mv_linear_mid_m_partial")
     return out
+
+
+# ---------------------------------------------------------------- K12: persistent small-batch decode
+class MvPersistArgs(ctypes.Structure):
+    """include/mvhip.h: MvPersistArgs (host struct, read at call time)."""
+    _fields_ = [("m", c_int), ("hidden", c_int), ("n_heads", c_int), ("n_kv_heads", c_int), ("head_dim", c_int),
+                ("inter", c_int), ("eps", c_float), ("scale", c_float), ("x_in", c_void_p), ("res_in", c_void_p),
+                ("x_in_stride", c_int64), ("res_in_stride", c_int64), ("positions", c_void_p),
+                ("slot_mapping", c_void_p), ("block_tables", c_void_p), ("context_lens", c_void_p),
+                ("table_stride", c_int64), ("num_blocks", c_int64), ("max_pos", c_int64), ("block_size", c_int),
+                ("max_blocks", c_int), ("cos", c_void_p), ("sin", c_void_p), ("out_h_offset", c_int64),
+                ("out_res_offset", c_int64)]
+
+
+PERSIST_LAYER_FIELDS = ("ln1_w", "wqkv", "bqkv", "q_norm_w", "k_norm_w", "wo", "ln2_w", "wgu", "wdown", "k_cache", "v_cache")
+PERSIST_MAX_ROWS = 16
+
+
+def persist_layer_table(rows, device) -> torch.Tensor:
+    """Device array of MvPersistLayer: ``rows`` = per layer a dict field -> tensor | None (PERSIST_LAYER_FIELDS)."""
+    flat = [[0 if r[f] is None else r[f].data_ptr() for f in PERSIST_LAYER_FIELDS] for r in rows]
+    return torch.tensor(flat, dtype=torch.int64).to(device)
+
+
+def decode_layers_persistent_workspace(m, hidden, n_heads, n_kv_heads, head_dim, inter, block_size, max_blocks, device):
+    n = int(_lib.mv_decode_layers_persistent_workspace_bytes(m, hidden, n_heads, n_kv_heads, head_dim, inter, block_size,
+                                                             max_blocks))
+    return torch.zeros(n, dtype=torch.uint8, device=device)
+
+
+def decode_layers_persistent(table, n_layers, x, positions, slot_mapping, block_tables, context_lens, cos, sin, k_cache0,
+                             n_heads, n_kv_heads, head_dim, inter, eps, scale, workspace, status, flags: int = 0):
+    """Every decoder layer of a decode step of <= 16 rows in ONE launch (csrc/decode_persistent.hip).  ``x`` [M, hidden] =
+    the embedding output.  -> (h, residual): views of ``workspace`` holding the last layer's down_proj output and the
+    residual (the caller applies the final norm), or None when the kernel does not take the shape (MV_E_SHAPE)."""
+    _need_cuda(x, positions, slot_mapping, block_tables, context_lens, cos, sin, workspace, status)
+    m, hidden = x.shape
+    bt = _i32(block_tables)
+    if bt.dim() != 2 or bt.stride(1) != 1 or x.stride(1) != 1 or positions.dtype != torch.int64:
+        return None
+    a = MvPersistArgs()
+    a.m, a.hidden, a.n_heads, a.n_kv_heads, a.head_dim, a.inter = m, hidden, n_heads, n_kv_heads, head_dim, inter
+    a.eps, a.scale = float(eps), float(scale)
+    a.x_in, a.res_in, a.x_in_stride, a.res_in_stride = x.data_ptr(), None, x.stride(0), 0
+    a.positions, a.slot_mapping = positions.data_ptr(), _i32(slot_mapping).data_ptr()
+    a.block_tables, a.context_lens = bt.data_ptr(), _i32(context_lens).data_ptr()
+    a.table_stride, a.num_blocks, a.max_pos = bt.stride(0), k_cache0.shape[0], cos.shape[0]
+    a.block_size, a.max_blocks = k_cache0.shape[1], bt.shape[1]
+    a.cos, a.sin = cos.data_ptr(), sin.data_ptr()
+    rc = _lib.mv_decode_layers_persistent(table.data_ptr(), n_layers, ctypes.byref(a), workspace.data_ptr(),
+                                          workspace.numel(), status.data_ptr(), _dt(x), int(flags), _stream())
+    if rc == MV_E_SHAPE:
+        return None
+    _check(rc, "mv_decode_layers_persistent")
+    esz = x.element_size()
+    h = workspace[a.out_h_offset:a.out_h_offset + m * hidden * esz].view(x.dtype).view(m, hidden)
+    r = workspace[a.out_res_offset:a.out_res_offset + m * hidden * esz].view(x.dtype).view(m, hidden)
+    return h, r
 
 
 # ---------------------------------------------------------------- f2
