@@ -277,6 +277,10 @@ def decode_roofline(engine, args, model=None):
     real_dist_ar = dist.all_reduce
     was_eager = ex.enforce_eager
     ex.enforce_eager = True
+    # (steps of <= 16 rows run all layers in one persistent launch: the probe times the attention kernel on its own, so
+    #  its steps take the multi-launch path, which computes the same bits)
+    from minivllm_amd.glue import qwen as _qwen
+    was_persistent, _qwen.PERSISTENT = _qwen.PERSISTENT, False
     # (Events cannot be recorded inside a captured graph on ROCm — "External events are disallowed in rocm",
     # tools/dbg/ext_event_probe.py — so the probe steps are eager.  Keeping the host ahead of the GPU with a spin
     # kernel in front of each probe step changes nothing (180 vs 178 us): what an event pair adds to the ~168 us
@@ -301,6 +305,7 @@ def decode_roofline(engine, args, model=None):
             delattr(ar, name)               # the instance attribute shadowed the method
         dist.all_reduce = real_dist_ar
         ex.enforce_eager = was_eager
+        _qwen.PERSISTENT = was_persistent
     torch.cuda.synchronize()
     times = [t * 1e-3 for t in probe.times_us("decode")]      # ms
     assert len(times) == probe_steps * L
@@ -827,7 +832,7 @@ def run_records(args, workdir, dist):
             sampling = SAMPLED if item["sampling"] == "sampled" else None
             rec, tps = decode_record(engine, engine_args, model, dist, sampling=sampling, seed=0 if first_on_engine else 2,
                                      probes=sampling is None)
-            if sampling is None:
+            if sampling is None and engine_args.batch > 16:
                 note("  projection roofline (graph replays)")
                 release_all(engine)
                 rec["projection_roofline"] = projection_roofline(engine, engine_args.batch)
