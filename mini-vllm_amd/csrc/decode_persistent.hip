@@ -24,7 +24,7 @@
 // byte that another workgroup reads is stored write-through and loaded with an sc1 load (paged_decode.h: ld16<true> ...),
 // the storing waves drain and meet at a workgroup barrier before lane 0 arrives.  Every spin is bounded; a give-up is
 // recorded in the status word and every later barrier returns at once (the launch drains, its results are garbage, the host
-// raises).  The barrier state is zeroed by a memset node in front of the launch.  One workgroup per CU, all resident.
+// raises).  The barrier state is zeroed by a one-workgroup launch in front.  One workgroup per CU, all resident.
 #include "paged_decode_body.h"
 
 #include <mutex>
@@ -53,7 +53,6 @@ constexpr int kThreads = 512, kWaves = 8, kStreamWaves = 7;   // wave 0 polls th
 constexpr int kChunkSteps = 8;                                  // k-steps (32 elements) of one weight tile per chunk
 constexpr int kChunkBytes = kChunkSteps * 1024;                 // 8 KiB: 16 rows x 256 elements
 constexpr int kMaxSlices = 16;
-constexpr unsigned kSpinLimit = 1u << 22;
 
 struct BarState {             // one 128-byte line per word that is polled or added to; zeroed before every launch
   unsigned census[8][32];     // workgroups per XCC
@@ -84,20 +83,30 @@ struct Params {
   int64_t off_res0, off_res1, off_h, off_qkv, off_attn, off_o, off_act, off_wsacc, off_wsml;
   DecodeParams dp;                     // attention: everything but the per-layer pointers
   int att_gx, att_gy;                  // grid of the decode kernel (kv-head groups, splits); z = M
-  unsigned *status;                    // [0] give-ups
+  unsigned *status;                    // [0] give-ups, [1..3] record of the first wait that expired (spin_until_ge)
+  int stamp_layer;                     // >= 0: workgroup 1 stamps s_memrealtime at the phase edges of this layer into status[8..]
 };
 
 __device__ __forceinline__ unsigned ld_rlx(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_rlx(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned add_rlx(unsigned *p, unsigned v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ void spin_until_ge(unsigned *p, unsigned want, BarState *st) {
-  for (unsigned it = 0; it < kSpinLimit; ++it) {
-    if (ld_rlx(p) >= want) return;
-    if ((it & 63) == 63 && ld_rlx(st->giveup) != 0) return;
+// Bounded in WALL-CLOCK time (s_memrealtime, 100 MHz): 2 s.  The first wait that expires records who / where / what it saw
+// (status words 1..3: epoch, workgroup, value seen) and raises the give-up word; every later wait returns at once.
+__device__ __forceinline__ void spin_until_ge(unsigned *p, unsigned want, BarState *st, unsigned *status, unsigned where) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned seen = 0;
+  for (unsigned it = 0;; ++it) {
+    if ((seen = ld_rlx(p)) >= want) return;
+    if ((it & 63) == 63) {
+      if (ld_rlx(st->giveup) != 0) return;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
+    }
     __builtin_amdgcn_s_sleep(1);
   }
-  st_rlx(st->giveup, 1u);
+  if (__hip_atomic_exchange(st->giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+    status[1] = where, status[2] = want, status[3] = seen;
+  }
 }
 
 // LDS-DMA of one 1-KiB weight fragment (64 lanes x 16 B, contiguous in the packed copy) into this wave's ring
@@ -110,6 +119,7 @@ struct Ctx {                   // per-workgroup constants
   BarState *bar;
   unsigned xcc, xcd_size, n_xcd, epoch;
   int nwg, wg, tid, wave, lane;
+  unsigned *status;
   char *ring;                  // [kStreamWaves][npre][kChunkBytes]
   char *scratch;               // phase-local LDS behind the ring
 };
@@ -176,7 +186,7 @@ __device__ __forceinline__ void grid_barrier(Ctx &c, PF prefetch) {
         for (unsigned x = 0; x < 8; ++x) st_rlx(st->gen[x], c.epoch);
       }
     }
-    spin_until_ge(st->gen[c.xcc], c.epoch, st);
+    spin_until_ge(st->gen[c.xcc], c.epoch, st, c.status, (c.epoch << 16) | (unsigned)c.wg);
   }
   __syncthreads();
 }
@@ -372,6 +382,13 @@ __device__ __forceinline__ void projection(const Params &p, const Ctx &c, const 
   else projection_cs<Tag, NORM, GATED, 4>(p, c, pj, w_packed, bias, xs, x, x_stride, out, out_stride, red4, npre);
 }
 
+// The barrier state is zeroed by a launch of its own in front of the persistent kernel.  (A hipMemsetAsync node did this in the
+// first version: replayed from a captured graph on ROCm 7.2 it filled the block with the low word of an address instead
+// of 0 — every counter started at 0xd0252800 — found with tools/dbg/persist_dbg.py; eager launches were fine.)
+__global__ void __launch_bounds__(256) zero_state_kernel(unsigned *words, int n) {
+  for (int i = threadIdx.x; i < n; i += 256) words[i] = 0u;
+}
+
 template <typename Tag, int D, int G, bool WIDE>
 __global__ void __launch_bounds__(kThreads) decode_layers_persistent_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -382,6 +399,7 @@ __global__ void __launch_bounds__(kThreads) decode_layers_persistent_kernel(Para
   c.nwg = gridDim.x, c.wg = blockIdx.x, c.tid = threadIdx.x, c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   c.lane = threadIdx.x & 63;
   c.epoch = 0;
+  c.status = p.status;
   c.ring = smem;
   c.scratch = smem + (size_t)kStreamWaves * p.npre * kChunkBytes;
   // census: workgroups per XCC (placement is not promised by HIP: counted, not assumed)
@@ -390,7 +408,7 @@ __global__ void __launch_bounds__(kThreads) decode_layers_persistent_kernel(Para
     s_xcc = xcc;
     add_rlx(c.bar->census[xcc], 1u);
     add_rlx(c.bar->flat, 1u);
-    spin_until_ge(c.bar->flat, (unsigned)c.nwg, c.bar);
+    spin_until_ge(c.bar->flat, (unsigned)c.nwg, c.bar, p.status, 0xffff0000u | (unsigned)blockIdx.x);
     unsigned nx = 0;
     for (unsigned x = 0; x < 8; ++x) nx += ld_rlx(c.bar->census[x]) != 0;
     s_size = ld_rlx(c.bar->census[xcc]);
@@ -409,13 +427,20 @@ __global__ void __launch_bounds__(kThreads) decode_layers_persistent_kernel(Para
   const int K = p.hidden;
   auto none = [] {};
 
+  // diagnostic (flags bit 8): wall-clock stamps (100 MHz) of one workgroup at the phase edges of one layer, low 32 bits, into
+  // status[8 + i] — memory nothing else reads
+  auto stamp = [&](int l, int i) {
+    if (p.stamp_layer == l && c.wg == 1 && threadIdx.x == 64) p.status[8 + i] = (unsigned)__builtin_amdgcn_s_memrealtime();
+  };
   for (int l = 0; l < p.n_layers; ++l) {
     MvPersistLayer L = gptr(p.layers)[l];
     L.ln1_w = gptr(L.ln1_w), L.wqkv = gptr(L.wqkv), L.bqkv = gptr(L.bqkv), L.q_norm_w = gptr(L.q_norm_w);
     L.k_norm_w = gptr(L.k_norm_w), L.wo = gptr(L.wo), L.ln2_w = gptr(L.ln2_w), L.wgu = gptr(L.wgu), L.wdown = gptr(L.wdown);
     L.k_cache = gptr(L.k_cache), L.v_cache = gptr(L.v_cache);
     // ---- A: input norm + qkv
+    stamp(l, 0);
     if (l > 0) grid_barrier(c, [&] { issue_prefetch<false>(p.qkv, L.wqkv, c, p.npre); });
+    stamp(l, 1);
     {
       const void *x = l == 0 ? p.x_in : ws + p.off_h;
       const int64_t xst = l == 0 ? p.x_in_stride : K;
@@ -424,10 +449,13 @@ __global__ void __launch_bounds__(kThreads) decode_layers_persistent_kernel(Para
       if (p.norm_pt <= 1) norm_rows<Tag, 1>(p, c, x, xst, res, rst, ws + p.off_res0, L.ln1_w, nred, xs, l > 0);
       else if (p.norm_pt == 2) norm_rows<Tag, 2>(p, c, x, xst, res, rst, ws + p.off_res0, L.ln1_w, nred, xs, l > 0);
       else norm_rows<Tag, 4>(p, c, x, xst, res, rst, ws + p.off_res0, L.ln1_w, nred, xs, l > 0);
+      stamp(l, 2);
       projection<Tag, true, false>(p, c, p.qkv, L.wqkv, L.bqkv, xs, nullptr, 0, ws + p.off_qkv, p.nqkv, red4, p.npre);
     }
+    stamp(l, 3);
     // ---- B: head norms + RoPE + K/V store + attention partials (the o_proj weights start streaming now)
     grid_barrier(c, [&] { issue_prefetch<false>(p.o, L.wo, c, p.npre); });
+    stamp(l, 4);
     {
       DecodeParams dp = p.dp;
       const uint16_t *qkv = (const uint16_t *)(ws + p.off_qkv);
@@ -446,9 +474,11 @@ __global__ void __launch_bounds__(kThreads) decode_layers_persistent_kernel(Para
         __syncthreads();
       }
     }
+    stamp(l, 5);
     // ---- C: split-KV combine
     if (p.dp.nsplit > 1) {
       grid_barrier(c, none);
+      stamp(l, 6);
       const int total = p.M * p.dp.n_heads, slot = c.tid >> 7;
       for (int base = 0; base < total; base += 4 * c.nwg) {
         const int vi = base + slot * c.nwg + c.wg;
@@ -460,23 +490,31 @@ __global__ void __launch_bounds__(kThreads) decode_layers_persistent_kernel(Para
       }
     }
     // ---- D: o_proj
+    stamp(l, 7);
     grid_barrier(c, none);
+    stamp(l, 8);
     projection<Tag, false, false>(p, c, p.o, L.wo, nullptr, nullptr, ws + p.off_attn, p.q_size, ws + p.off_o, K, red4, p.npre);
+    stamp(l, 9);
     // ---- E: post-attention norm + gate_up + SiluAndMul
     grid_barrier(c, [&] { issue_prefetch<true>(p.gu, L.wgu, c, p.npre); });
+    stamp(l, 10);
     if (p.norm_pt <= 1) norm_rows<Tag, 1>(p, c, ws + p.off_o, K, ws + p.off_res0, K, ws + p.off_res1, L.ln2_w, nred, xs, true);
     else if (p.norm_pt == 2) norm_rows<Tag, 2>(p, c, ws + p.off_o, K, ws + p.off_res0, K, ws + p.off_res1, L.ln2_w, nred, xs, true);
     else norm_rows<Tag, 4>(p, c, ws + p.off_o, K, ws + p.off_res0, K, ws + p.off_res1, L.ln2_w, nred, xs, true);
+    stamp(l, 11);
     projection<Tag, true, true>(p, c, p.gu, L.wgu, nullptr, xs, nullptr, 0, ws + p.off_act, p.inter, red4, p.npre);
+    stamp(l, 12);
     // ---- F: down_proj
     grid_barrier(c, [&] { issue_prefetch<false>(p.down, L.wdown, c, p.npre); });
+    stamp(l, 13);
     projection<Tag, false, false>(p, c, p.down, L.wdown, nullptr, nullptr, ws + p.off_act, p.inter, ws + p.off_h, K, red4, p.npre);
+    stamp(l, 14);
   }
   if (threadIdx.x == 0 && blockIdx.x == 0) p.status[0] = ld_rlx(c.bar->giveup);
 }
 
 // linear_small_m.hip: run<GATED, PACKED>'s launch plan for <= 16 rows on the packed copy: (K slices, block size in k-steps)
-void small_m_plan(int n, int k, bool gated, int *nslices, int *kU, int *rpw_out) {
+void small_m_plan(int m, int n, int k, bool gated, int *nslices, int *kU, int *rpw_out) {
   const int mt = 1, steps = k / 32;
   const int rpw = gated ? 1 : (n > 4096 ? 2 : 1);
   const int na = gated ? 2 * rpw : rpw;
@@ -490,6 +528,12 @@ void small_m_plan(int n, int k, bool gated, int *nslices, int *kU, int *rpw_out)
     }
   if (waves > nblk) waves = nblk;
   while (waves > 1 && waves * na * mt > 64) --waves;
+  // from 12 rows up that launch stages x through LDS (one block of `unroll` k-steps x 16 rows per wave, 64 KB in all):
+  // fewer, longer K slices where the waves' blocks would not fit (down_proj of Qwen3-1.7B: 12 -> 6 slices)
+  if (m >= 12 && rpw < 4) {
+    const size_t xblock = (size_t)mt * 16 * unroll * 64;
+    while (waves > 1 && waves * xblock > 65536) waves /= 2;
+  }
   *nslices = waves, *kU = unroll, *rpw_out = rpw;
 }
 
@@ -564,7 +608,7 @@ extern "C" int mv_decode_layers_persistent(const MvPersistLayer *layers_dev, int
   int rpw;
   auto plan = [&](Proj &pj, int n, int k, bool gated) {
     pj.n = n, pj.n_tiles = (n + 15) / 16, pj.K = k;
-    small_m_plan(n, k, gated, &pj.nslices, &pj.kU, &rpw);
+    small_m_plan(m, n, k, gated, &pj.nslices, &pj.kU, &rpw);
     if (rpw != 1 || pj.nslices > kMaxSlices || k / 32 < pj.kU || (k / 32) % pj.kU) return false;
     // every slice is a whole number of kU-step blocks; chunks of 8 steps where every slice allows it, else of 4
     pj.cs = 8;
@@ -613,6 +657,7 @@ extern "C" int mv_decode_layers_persistent(const MvPersistLayer *layers_dev, int
   const int hg = wide ? 4 : 1;
   const size_t att_scratch = 1024 + 2 * (size_t)(4 * hg * g * 2 + 4 * hg * g * D) * 4;   // 2 slots of the decode body
   const size_t scratch = proj_scratch > att_scratch ? proj_scratch : att_scratch;
+  p.stamp_layer = (flags & 0x100) ? (n_layers > 1 ? 1 : 0) : -1;   // flags bit 8: phase stamps of layer 1 (diagnostic)
   int npre = (flags & 0xff) == 0xff ? 0 : ((flags & 0xff) ? (flags & 0xff) : 2);    // flags bits 0-7: chunks in flight per wave (0xff = none)
   constexpr size_t kLdsMax = 160 * 1024 - 256;   // (the kernel's 16 static bytes in front)
   while (npre > 0 && (size_t)kStreamWaves * npre * kChunkBytes + scratch > kLdsMax) --npre;
@@ -622,7 +667,7 @@ extern "C" int mv_decode_layers_persistent(const MvPersistLayer *layers_dev, int
   const int cus = device_cus();
   if (cus <= 0) return MV_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  if (int e = mv_check_hip(hipMemsetAsync(workspace, 0, align256(sizeof(BarState)), st))) return e;
+  hipLaunchKernelGGL(zero_state_kernel, dim3(1), dim3(256), 0, st, (unsigned *)workspace, (int)(align256(sizeof(BarState)) / 4));
 #define MV_PERSIST(TAG, GG, WW)                                                                                     \
   do {                                                                                                              \
     auto kern = decode_layers_persistent_kernel<TAG, 128, GG, WW>;                                                  \

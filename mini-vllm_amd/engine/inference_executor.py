@@ -264,10 +264,14 @@ class InferenceExecutor:
         """Small decode steps run every layer in one persistent launch whose grid barriers are bounded waits
         (csrc/decode_persistent.hip): a wait that gave up means the step's activations are garbage.  The status word came
         back with the step (glue/qwen.py copies it behind the launch); the tokens have been read, so it is current."""
-        fn = getattr(getattr(self.model, "model", None), "persistent_give_ups", None)
+        inner = getattr(self.model, "model", None)
+        fn = getattr(inner, "persistent_give_ups", None)
         if fn is not None and fn():
-            raise RuntimeError("persistent decode launch: a grid-barrier wait gave up (workgroups not co-resident or a "
-                               "device fault); the results of this step are invalid.  MV_PERSISTENT=0 selects the "
+            w = inner.persistent_status()
+            where = "the start-up census" if w[1] >> 16 == 0xFFFF else f"grid barrier #{w[1] >> 16}"
+            raise RuntimeError(f"persistent decode launch: a bounded wait gave up after 2 s at {where} on workgroup "
+                               f"{w[1] & 0xFFFF} (waiting for {w[2]}, last saw {w[3]}): workgroups not co-resident or a "
+                               "device fault; the results of this step are invalid.  MV_PERSISTENT=0 selects the "
                                "multi-launch path")
 
     def _to_dev(self, t: torch.Tensor | None):

@@ -104,6 +104,8 @@ PERSISTENT = os.environ.get("MV_PERSISTENT", "1") != "0"
 PERSISTENT_FLAGS = {"none": 0xff}.get(os.environ.get("MV_PERSISTENT_PREFETCH", ""), None)
 if PERSISTENT_FLAGS is None:
     PERSISTENT_FLAGS = int(os.environ.get("MV_PERSISTENT_PREFETCH", "0") or 0)
+if os.environ.get("MV_PERSISTENT_STAMPS") == "1":
+    PERSISTENT_FLAGS |= 0x100
 
 
 class QwenAttention(nn.Module):
@@ -298,8 +300,8 @@ class QwenModel(nn.Module):
                                  wdown=mlp.down_proj.weight_packed, k_cache=at.attn.k_cache, v_cache=at.attn.v_cache))
             st = self._persist = dict(
                 key=key, table=hip_ops.persist_layer_table(rows, x.device), keep=rows,
-                status=torch.zeros(4, dtype=torch.int32, device=x.device),
-                status_host=torch.zeros(4, dtype=torch.int32).pin_memory(), ws={})
+                status=torch.zeros(32, dtype=torch.int32, device=x.device),
+                status_host=torch.zeros(32, dtype=torch.int32).pin_memory(), ws={})
         return st
 
     def _forward_persistent(self, hidden_states, positions):
@@ -337,6 +339,20 @@ class QwenModel(nn.Module):
         step has completed (the executor asks after it has read the step's tokens)."""
         st = getattr(self, "_persist", None)
         return 0 if st is None else int(st["status_host"][0])
+
+    def persistent_status(self) -> list[int]:
+        """The four status words of the persistent launch: give-ups, then the first expired wait: (barrier epoch << 16 |
+        workgroup; 0xffff.... = the start-up census), the value waited for, the value last seen."""
+        st = getattr(self, "_persist", None)
+        return [0, 0, 0, 0] if st is None else [int(v) & 0xFFFFFFFF for v in st["status_host"][:4]]
+
+    def persistent_stamps(self) -> list[float]:
+        """(MV_PERSISTENT_PREFETCH flags bit 8) microseconds between the phase edges of layer 1 as workgroup 1 saw them."""
+        st = getattr(self, "_persist", None)
+        if st is None:
+            return []
+        t = [int(v) & 0xFFFFFFFF for v in st["status_host"][8:23]]
+        return [((b - a) & 0xFFFFFFFF) / 100.0 for a, b in zip(t, t[1:])]
 
     def forward(self, input_ids, positions):
         hidden_states, residual, pending = self.embed_tokens(input_ids), None, False

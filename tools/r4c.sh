@@ -2,7 +2,7 @@
 # round 4, third GPU call: the persistent small-batch decode kernel — parity first (bounded by timeout), then timing
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_persistent.py -x -q > gpurun_out/r4c_pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"
+timeout -k 10 900 python -m pytest tests/test_gpu_persistent.py -q > gpurun_out/r4c_pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"
 tail -25 gpurun_out/r4c_pytest.log
 if [ $rc -ne 0 ]; then exit $rc; fi
 for b in 1 8; do
