@@ -98,9 +98,11 @@ ROPE_FOLD = os.environ.get("MV_ROPE_FOLD", "1") != "0"
 # separate launch cost (7.00 ms both ways), so larger steps keep mv_rope_qk_store
 ROPE_FOLD_MAX_ROWS = int(os.environ.get("MV_ROPE_FOLD_MAX", "128"))
 # decode steps of <= 16 rows: every decoder layer in ONE persistent launch (csrc/decode_persistent.hip), bit-identical to
-# the multi-launch path.  MV_PERSISTENT=0 keeps the launches; MV_PERSISTENT_PREFETCH = weight chunks per wave in flight
-# across a barrier (default 2, "none" = 0xff)
-PERSISTENT = os.environ.get("MV_PERSISTENT", "1") != "0"
+# the multi-launch path.  OFF by default: measured SLOWER than the six launches per layer it replaces (round 4, Qwen3-1.7B:
+# B = 1 1.55 vs 1.26 ms per step, B = 8 2.23 vs 1.65 — profiles/r04_persistent_decode.md says which phases lose);
+# MV_PERSISTENT=1 selects it.  MV_PERSISTENT_PREFETCH = weight chunks per wave in flight across a barrier (default 2,
+# "none" = 0xff); MV_PERSISTENT_STAMPS=1 = phase stamps (diagnostic)
+PERSISTENT = os.environ.get("MV_PERSISTENT", "0") == "1"
 PERSISTENT_FLAGS = {"none": 0xff}.get(os.environ.get("MV_PERSISTENT_PREFETCH", ""), None)
 if PERSISTENT_FLAGS is None:
     PERSISTENT_FLAGS = int(os.environ.get("MV_PERSISTENT_PREFETCH", "0") or 0)

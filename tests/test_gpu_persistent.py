@@ -166,7 +166,7 @@ def test_persistent_launch_in_a_graph_and_through_the_engine(tmp_path, monkeypat
             try:
                 results[(on, eager)] = [o["token_ids"] for o in llm.generate(prompts, sp, use_tqdm=False)]
                 inner = llm.model_runner.inference_executor.model.model
-                assert (getattr(inner, "_persist", None) is not None) == on
+                assert (getattr(inner, "_persist", None) is not None) == on   # (off is the default: MV_PERSISTENT=1 selects it)
                 assert inner.persistent_give_ups() == 0
                 if not eager:
                     assert llm.model_runner.inference_executor.spec_hits > 0
