@@ -46,11 +46,12 @@ struct LinearParams {
   int norm_threads = 0;  // block size of the rmsnorm_kernel launch this prologue re-enacts
 };
 
-constexpr int kNormRedBytes = 256;  // [4 rows][16 waves] floats in front of the normalised rows
+constexpr int kNormRows = 8;        // rows the norm prologue takes (round 4: 8; rounds 2-3: 4)
+constexpr int kNormRedBytes = kNormRows * 16 * 4;  // [8 rows][16 waves] floats in front of the normalised rows
 __host__ __device__ constexpr int norm_row_bytes(int k) { return k * 2 + 64; }  // (+64: rows 0..3 on disjoint banks)
 
 // NORM prologue: the residual-add + RMSNorm that the reference runs in front of this projection
-// (minivllm/models/layers/layernorm.py:81-105; rmsnorm.hip) re-enacted by EVERY workgroup for the <= 4 rows of a
+// (minivllm/models/layers/layernorm.py:81-105; rmsnorm.hip) re-enacted by EVERY workgroup for the <= 8 rows of a
 // small decode step — a few KB from L2 — so that the norm needs no launch of its own.  The arithmetic is
 // rmsnorm_kernel's, thread for thread: a block of `norm_threads` threads, thread t owning the 8-element vectors
 // t, t + T, ..., the same fmaf chain, wave_sum, and wave-order sum, the same rounding points (the norm is taken
@@ -58,65 +59,74 @@ __host__ __device__ constexpr int norm_row_bytes(int k) { return k * 2 + 64; }  
 // to a buffer of its own: the other workgroups still read the old one).  The normalised rows land in LDS.
 template <typename Tag, int PT>
 __device__ __forceinline__ void norm_prologue(const LinearParams &p, float *nred, char *xs) {
-  constexpr int ROWS = 4 / PT;
+  constexpr int ROWS = 4 / PT;   // rows per pass: their vectors live in registers between the two halves of the pass
   const int T = p.norm_threads, nvec = p.K >> 3, tid = threadIdx.x, nw = T >> 6;
   const uint16_t *x = (const uint16_t *)p.x, *res = (const uint16_t *)p.nres, *w = (const uint16_t *)p.nw;
   uint16_t *res_out = (uint16_t *)p.nres_out;
   const bool add = res != nullptr;
-  u32x4 xraw[ROWS][PT], rraw[ROWS][PT], wraw[PT];
+  u32x4 wraw[PT];
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
     const int c = tid + i * T;
-    const bool live = tid < T && c < nvec;
-    wraw[i] = live ? *(const u32x4 *)(w + c * 8) : u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      const bool on = live && r < p.M;
-      xraw[r][i] = on ? *(const u32x4 *)(x + (int64_t)r * p.x_stride + c * 8) : u32x4{0u, 0u, 0u, 0u};
-      rraw[r][i] = on && add ? *(const u32x4 *)(res + (int64_t)r * p.nres_stride + c * 8) : u32x4{0u, 0u, 0u, 0u};
-    }
+    wraw[i] = (tid < T && c < nvec) ? *(const u32x4 *)(w + c * 8) : u32x4{0u, 0u, 0u, 0u};
   }
-  float vals[ROWS][PT][8];
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r) {
-    float ss = 0.f;
+  // round 4: more than ROWS rows (up to kNormRows) go through in passes of ROWS; a pass only touches its own rows' sums, so one
+  // barrier per pass (between the sums and their use) is enough
+  for (int r0 = 0; r0 < p.M; r0 += ROWS) {
+    u32x4 xraw[ROWS][PT], rraw[ROWS][PT];
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       const int c = tid + i * T;
-      const bool on = tid < T && c < nvec && r < p.M;
-      unpack8<Tag>(xraw[r][i], vals[r][i]);
-      if (add) {
-        float rr[8];
-        unpack8<Tag>(rraw[r][i], rr);
+      const bool live = tid < T && c < nvec;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vals[r][i][j] = __fadd_rn(vals[r][i][j], rr[j]);
-        if (on && blockIdx.x == 0) *(u32x4 *)(res_out + (int64_t)r * p.nres_out_stride + c * 8) = pack8<Tag>(vals[r][i]);
-      }
-      if (on) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ss = fmaf(vals[r][i][j], vals[r][i][j], ss);
+      for (int r = 0; r < ROWS; ++r) {
+        const bool on = live && r0 + r < p.M;
+        xraw[r][i] = on ? *(const u32x4 *)(x + (int64_t)(r0 + r) * p.x_stride + c * 8) : u32x4{0u, 0u, 0u, 0u};
+        rraw[r][i] = on && add ? *(const u32x4 *)(res + (int64_t)(r0 + r) * p.nres_stride + c * 8) : u32x4{0u, 0u, 0u, 0u};
       }
     }
-    ss = wave_sum(ss);
-    if ((tid & 63) == 0 && (tid >> 6) < nw) nred[r * 16 + (tid >> 6)] = ss;
-  }
-  __syncthreads();
+    float vals[ROWS][PT][8];
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r) {
-    if (r < p.M && tid < T) {
-      float t = nred[r * 16];
-      for (int i = 1; i < nw; ++i) t += nred[r * 16 + i];   // block_sum: 0.f + red[0] + red[1] + ...
-      const float var = t / (float)p.K;
-      const float rs = 1.0f / sqrtf(var + p.eps);
+    for (int r = 0; r < ROWS; ++r) {
+      float ss = 0.f;
 #pragma unroll
       for (int i = 0; i < PT; ++i) {
         const int c = tid + i * T;
-        if (c < nvec) {
-          float wv[8], y[8];
-          unpack8<Tag>(wraw[i], wv);
+        const bool on = tid < T && c < nvec && r0 + r < p.M;
+        unpack8<Tag>(xraw[r][i], vals[r][i]);
+        if (add) {
+          float rr[8];
+          unpack8<Tag>(rraw[r][i], rr);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) y[j] = __fmul_rn(__fmul_rn(vals[r][i][j], rs), wv[j]);
-          *(u32x4 *)(xs + r * norm_row_bytes(p.K) + c * 16) = pack8<Tag>(y);
+          for (int j = 0; j < 8; ++j) vals[r][i][j] = __fadd_rn(vals[r][i][j], rr[j]);
+          if (on && blockIdx.x == 0) *(u32x4 *)(res_out + (int64_t)(r0 + r) * p.nres_out_stride + c * 8) = pack8<Tag>(vals[r][i]);
+        }
+        if (on) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ss = fmaf(vals[r][i][j], vals[r][i][j], ss);
+        }
+      }
+      ss = wave_sum(ss);
+      if ((tid & 63) == 0 && (tid >> 6) < nw && r0 + r < p.M) nred[(r0 + r) * 16 + (tid >> 6)] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      if (r0 + r < p.M && tid < T) {
+        float t = nred[(r0 + r) * 16];
+        for (int i = 1; i < nw; ++i) t += nred[(r0 + r) * 16 + i];   // block_sum: 0.f + red[0] + red[1] + ...
+        const float var = t / (float)p.K;
+        const float rs = 1.0f / sqrtf(var + p.eps);
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+          const int c = tid + i * T;
+          if (c < nvec) {
+            float wv[8], y[8];
+            unpack8<Tag>(wraw[i], wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = __fmul_rn(__fmul_rn(vals[r][i][j], rs), wv[j]);
+            *(u32x4 *)(xs + (r0 + r) * norm_row_bytes(p.K) + c * 16) = pack8<Tag>(y);
+          }
         }
       }
     }
@@ -430,7 +440,7 @@ int run(LinearParams p, int dtype, int shape, hipStream_t st) {
     int nt, npt;
     norm_block(p.K, &nt, &npt);
     const int pt = npt <= 1 ? 1 : (npt == 2 ? 2 : 4);
-    if (mt != 1 || npt > 4 || m * pt > 4 || waves * 64 < nt || (p.K & 7)) return MV_E_SHAPE;
+    if (mt != 1 || npt > 4 || m * pt > kNormRows || waves * 64 < nt || (p.K & 7)) return MV_E_SHAPE;
     p.norm_threads = nt;
     size_t lds = (size_t)waves * na * 64 * sizeof(f32x4);
     const size_t need = kNormRedBytes + (size_t)m * norm_row_bytes(p.K);
@@ -557,7 +567,7 @@ extern "C" int mv_gate_up_silu_small_m_packed(const void *x, int64_t x_stride, c
 static int norm_check(const void *x, int64_t x_stride, const void *residual, int64_t res_stride, void *residual_out,
                       int64_t res_out_stride, const void *norm_w, int m, int k) {
   if (!norm_w || (residual && !residual_out)) return MV_E_NULLPTR;
-  if (m > 4 || k > 8192) return MV_E_SHAPE;
+  if (m > kNormRows || k > 8192) return MV_E_SHAPE;
   if (!mv_aligned16(norm_w) || (residual && (!mv_aligned16(residual) || !mv_aligned16(residual_out) ||
                                              (res_stride & 7) || (res_out_stride & 7))))
     return MV_E_ALIGN;

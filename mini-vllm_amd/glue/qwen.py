@@ -84,7 +84,7 @@ class PendingNorm:
 
 
 def _fold_norm(x, residual, lin) -> bool:
-    """Fold the layer norm in front of ``lin`` into its launch?  Single GPU, 2-D activations of <= 4 rows whose
+    """Fold the layer norm in front of ``lin`` into its launch?  Single GPU, 2-D activations of <= 4 rows (8 with MV_NORM_FOLD_MAX_ROWS=8: measured slower) whose
     projection runs on the packed weight (csrc/linear_small_m.hip, norm_prologue)."""
     return (NORM_FOLD and torch.is_tensor(x) and get_tensor_parallel_world_size() == 1
             and (residual is None or torch.is_tensor(residual))

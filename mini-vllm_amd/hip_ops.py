@@ -535,7 +535,11 @@ def gate_up_silu_small_m(x, weight, shape: int = 0, packed=None):
     return out.view(*x.shape[:-1], n)
 
 
-NORM_FUSED_MAX_ROWS = 4
+# rows x vectors-per-norm-thread up to which the layer norm rides in the prologue of the small-M projection behind it.  The
+# kernel takes up to 8 (csrc/linear_small_m.hip: kNormRows, in passes of 4 / PT rows, round 4), but beyond one pass the
+# prologue costs more than the norm launch it saves — Qwen3-1.7B, ctx 1024: B = 5 1.52 -> 1.61 ms per step, B = 8 1.66 ->
+# 1.81 (gpurun_out/r4e_*) — so the default stays at one pass (4); MV_NORM_FOLD_MAX_ROWS=8 selects the longer fold
+NORM_FUSED_MAX_ROWS = min(8, int(os.environ.get("MV_NORM_FOLD_MAX_ROWS", "4")))
 
 
 def norm_linear_small_m_ok(x, n_rows_w: int, packed) -> bool:
@@ -550,7 +554,7 @@ def norm_linear_small_m_ok(x, n_rows_w: int, packed) -> bool:
     threads = min(256, -(-nvec // 64) * 64)
     per_thread = -(-nvec // threads)
     pt = 1 if per_thread <= 1 else (2 if per_thread == 2 else 4)
-    return rows * pt <= 4 and _packed_ok(packed, n_rows_w, k, x.dtype)
+    return rows * pt <= NORM_FUSED_MAX_ROWS and _packed_ok(packed, n_rows_w, k, x.dtype)
 
 
 def norm_linear_small_m(x, residual, norm_weight, eps: float, weight_packed, n: int, bias=None, gated: bool = False):

@@ -3,6 +3,8 @@ CPU oracle on the same seeded inputs.  Integer/byte work is bit-exact; floating 
 held to the tolerance written next to each check."""
 import math
 
+import os
+
 import pytest
 import torch
 
@@ -873,12 +875,17 @@ def test_gate_up_silu_small_m_on_the_packed_weight(H, dtype, m, inter, k):
     (1, 4096, 2048, False, False), (4, 4096, 2048, True, False), (2, 4608, 3584, True, False),
     (1, 1280, 8192, True, False), (3, 3072, 1024, False, False), (1, 6144, 2048, False, True),
     (2, 18944, 3584, False, True), (4, 3072, 1024, False, True), (1, 152064, 3584, False, False),
+    # round 4: up to 8 rows, in passes of 4 / PT rows (K = 2048 / 1024: 4 per pass; K = 3584: 2 per pass -> 4 rows at most)
+    (5, 4096, 2048, False, False), (8, 4096, 2048, True, False), (7, 6144, 2048, False, True), (8, 6144, 2048, False, True),
+    (6, 3072, 1024, False, False), (4, 4608, 3584, True, False), (3, 18944, 3584, False, True),
 ])
 @pytest.mark.parametrize("with_residual", [True, False])
-def test_norm_folded_into_the_small_m_projection_is_bit_identical(H, dtype, m, n, k, bias, gated, with_residual):
+def test_norm_folded_into_the_small_m_projection_is_bit_identical(H, dtype, m, n, k, bias, gated, with_residual, monkeypatch):
     """mv_norm_linear_small_m_packed / mv_norm_gate_up_silu_small_m_packed: RMSNorm (+ residual add) in the
     prologue of the projection == mv_(add_)rmsnorm followed by the projection on the packed weight, bit for bit
-    (outputs AND the new residual), and the residual input is left untouched."""
+    (outputs AND the new residual), and the residual input is left untouched.  (The engine folds one pass of rows by
+    default; the two-pass cases run with the limit raised, as MV_NORM_FOLD_MAX_ROWS=8 does.)"""
+    monkeypatch.setattr(H, "NORM_FUSED_MAX_ROWS", 8)
     x = _randn(m, k, dtype=dtype, seed=m + n).to(DEV)
     res = _randn(m, k, dtype=dtype, seed=7).to(DEV) if with_residual else None
     nw = (1.0 + 0.1 * _randn(k, dtype=torch.float32, seed=3)).to(dtype).to(DEV)
@@ -937,10 +944,12 @@ def test_norm_folding_declines_what_it_cannot_hold(H):
     dtype = torch.bfloat16
     w = torch.zeros(256, 3584, dtype=dtype, device=DEV)
     wp = H.pack_weight(w)
+    assert H.NORM_FUSED_MAX_ROWS == 4 or os.environ.get("MV_NORM_FOLD_MAX_ROWS")
     assert not H.norm_linear_small_m_ok(torch.zeros(5, 3584, dtype=dtype, device=DEV), 256, wp)   # > 4 rows
     assert not H.norm_linear_small_m_ok(torch.zeros(3, 3584, dtype=dtype, device=DEV), 256, wp)   # 3 rows x 2 vectors
     assert H.norm_linear_small_m_ok(torch.zeros(2, 3584, dtype=dtype, device=DEV), 256, wp)
-    x = torch.zeros(3, 3584, dtype=dtype, device=DEV)
+    # the kernel itself takes two passes (round 4) and declines a third: 5 rows x 2 vectors per norm thread
+    x = torch.zeros(5, 3584, dtype=dtype, device=DEV)
     assert H.norm_linear_small_m(x, None, torch.ones(3584, dtype=dtype, device=DEV), 1e-6, wp, 256) is None
 
 
