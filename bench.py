@@ -109,6 +109,10 @@ def parse(argv=None):
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary records (the rest of BASELINE.json's metric: record_plan)")
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-baseline steps (median), after one warm-up")
+    ap.add_argument("--rehearse-n8", action="store_true",
+                    help="(with --gpus 2, ranks sharing one card) run the N = 8 record flow on stand-ins: a Qwen2-7B-like model "
+                         "whose heads do not divide by 2 (-> the rejection record) and a 4-layer model at Qwen2-72B's per-layer "
+                         "dimensions on an explicit KV pool; the records are marked as a rehearsal")
     ap.add_argument("--cpu-config1-only", action="store_true",
                     help="run only the CPU leg of BASELINE config 1 (OPT-125M fp32, reference preset) and print it")
     return ap.parse_args(argv)
@@ -127,7 +131,7 @@ def launch_command(args, script=None, port=None):
            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__),
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--model", args.model, "--batch", str(args.batch), "--ctx", str(args.ctx)]
-    for flag in ("eager", "synthetic_kv", "auto_kv", "no_cpu_baseline", "no_secondary"):
+    for flag in ("eager", "synthetic_kv", "auto_kv", "no_cpu_baseline", "no_secondary", "rehearse_n8"):
         if getattr(args, flag):
             cmd.append("--" + flag.replace("_", "-"))
     return cmd
@@ -780,6 +784,14 @@ def run_records(args, workdir, dist):
     import gc
 
     plan = record_plan(args.gpus, args.model, args.batch, args.ctx)
+    if args.rehearse_n8:
+        # the N = 8 flow (rejection, then a third engine with the 72B layer shape) on what two ranks on one card can hold
+        odd = dict(MODELS["qwen2-7b"], num_attention_heads=7, num_key_value_heads=1, hidden_size=896, num_hidden_layers=2)
+        MODELS["qwen2-7b-odd-heads (rehearsal)"] = odd
+        MODELS["qwen2-72b-4-layers (rehearsal)"] = dict(MODELS["qwen2-72b"], num_hidden_layers=4)
+        plan = [plan[0], dict(kind="rejected", model="qwen2-7b-odd-heads (rehearsal)", tp=args.gpus),
+                dict(kind="decode", model="qwen2-72b-4-layers (rehearsal)", tp=args.gpus, batch=256, ctx=1024, sampling="greedy",
+                     max_model_len=4096)]
     if args.no_secondary or args.synthetic_kv:
         plan = plan[:1]
     records, engine, engine_model, engine_args, first_on_engine = [], None, None, None, True
@@ -801,8 +813,9 @@ def run_records(args, workdir, dist):
             except ValueError as e:
                 records.append({"metric": "decode tokens/s", "model": model, "tp": item["tp"], "value": None,
                                 "status": "rejected, as in reference", "error": f"ValueError: {e}",
-                                "reference": "minivllm/models/qwen_base.py:95-104 (28 q heads / 4 kv heads do not divide by 8); "
-                                             "the build raises the same error instead of silently replicating KV heads"})
+                                "reference": "minivllm/models/qwen_base.py:95-104 (q / kv heads must divide by the TP degree: "
+                                             f"{MODELS[model]['num_attention_heads']} / {MODELS[model]['num_key_value_heads']} by "
+                                             f"{item['tp']}); the build raises the same error instead of silently replicating KV heads"})
             else:
                 eng.exit()
                 raise AssertionError(f"{model} at TP={item['tp']} was accepted: the reference rejects it")
