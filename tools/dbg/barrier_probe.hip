@@ -7,6 +7,8 @@
 //           is stored `sc1` and drained (s_waitcnt vmcnt(0) + workgroup barrier before the arrival), every payload
 //           load is an `sc1` load behind the poll + a workgroup barrier (guide, Valid forms, table row 1)
 //   mode 2  the same with the XCD leader's release fence and every workgroup's acquire fence, plain payload
+//   mode 3  per-XCC counters only: one lane adds to its XCC's counter (no return value needed), lanes 0..7 of the same wave
+//           poll the eight counters together until every one has all its arrivals: two fabric trips instead of three
 //   +4      a weight-like HBM stream between the barriers (every wave keeps 8 x 16 B x 64 lanes of loads in flight)
 // Every spin is bounded (give-up word); the state block is zeroed by a memset before every launch.
 // Build: hipcc -O3 --offload-arch=gfx950 -o barrier_probe.bin barrier_probe.hip ; run: ./barrier_probe.bin
@@ -57,9 +59,24 @@ __device__ __forceinline__ u32x4 load_sc1(const void *p) {
 
 template <int MODE>
 __device__ __forceinline__ void grid_barrier(State *st, unsigned epoch, unsigned xcc, unsigned my_xcd_size, unsigned n_xcd,
-                                             unsigned nwg) {
+                                             unsigned nwg, const unsigned *sizes = nullptr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its stores have left
   __syncthreads();
+  if (MODE == 3) {
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      if (lane == 0) __hip_atomic_fetch_add(st->xcd[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned want = lane < 8 ? sizes[lane] * epoch : 0u;
+      for (unsigned it = 0; it < (1u << 22); ++it) {
+        const unsigned seen = lane < 8 ? ld_rlx(st->xcd[lane]) : 0u;
+        if (__all(seen >= want)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (it == (1u << 22) - 1 && lane == 0) st_rlx(st->giveup, 1u);
+      }
+    }
+    __syncthreads();
+    return;
+  }
   if (threadIdx.x == 0) {
     if (MODE == 0) {
       add_rlx(st->flat, 1u);
@@ -90,7 +107,7 @@ template <int MODE, bool STREAM>
 __global__ void __launch_bounds__(512) probe(State *st, u32x4 *payload, const u32x4 *stream, size_t stream_vecs, int rounds,
                                               unsigned long long *out_cycles) {
   const unsigned nwg = gridDim.x, wg = blockIdx.x;
-  __shared__ unsigned s_xcc, s_size, s_nx;
+  __shared__ unsigned s_xcc, s_size, s_nx, s_sizes[8];
   if (threadIdx.x == 0) {
     unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 7;   // HW_REG_XCC_ID, bits 0..3
     s_xcc = xcc;
@@ -101,6 +118,7 @@ __global__ void __launch_bounds__(512) probe(State *st, u32x4 *payload, const u3
     for (unsigned x = 0; x < 8; ++x) nx += ld_rlx(st->census[x]) != 0;
     s_size = ld_rlx(st->census[xcc]);
     s_nx = nx;
+    for (unsigned x = 0; x < 8; ++x) s_sizes[x] = ld_rlx(st->census[x]);
   }
   __syncthreads();
   const unsigned xcc = s_xcc, xs = s_size, nx = s_nx;
@@ -119,10 +137,10 @@ __global__ void __launch_bounds__(512) probe(State *st, u32x4 *payload, const u3
     }
     if (wave == 0) {   // publish: 1 KiB per workgroup, every word = f(round, wg, lane)
       const u32x4 v = {(unsigned)r, wg, (unsigned)lane, (unsigned)r * 2654435761u + wg * 40503u + lane};
-      if (MODE == 2) payload[(size_t)wg * 64 + lane] = v;
+      if (MODE == 2) payload[(size_t)wg * 64 + lane] = v;   // (modes 0, 1, 3: write-through)
       else store_sc1(&payload[(size_t)wg * 64 + lane], v);
     }
-    grid_barrier<MODE>(st, (unsigned)r, xcc, xs, nx, nwg);
+    grid_barrier<MODE>(st, (unsigned)r, xcc, xs, nx, nwg, s_sizes);
     if (wave == 1) {   // consume the record of a workgroup on (most likely) another XCD
       const unsigned src = (wg + 1 + (r % 7)) % nwg;
       u32x4 v;
@@ -193,8 +211,10 @@ int main() {
   run<0, false>("mode 0: one counter, fence-free (sc1 payload)", st, payload, stream, vecs, cyc, nwg);
   run<1, false>("mode 1: XCD-hierarchical, fence-free (sc1 payload)", st, payload, stream, vecs, cyc, nwg);
   run<2, false>("mode 2: XCD-hierarchical, release + acquire fences", st, payload, stream, vecs, cyc, nwg);
+  run<3, false>("mode 3: per-XCC counters, 8-lane poll, fence-free", st, payload, stream, vecs, cyc, nwg);
   run<0, true>("mode 0 + HBM stream (64 KB per CU and round)", st, payload, stream, vecs, cyc, nwg);
   run<1, true>("mode 1 + HBM stream (64 KB per CU and round)", st, payload, stream, vecs, cyc, nwg);
   run<2, true>("mode 2 + HBM stream (64 KB per CU and round)", st, payload, stream, vecs, cyc, nwg);
+  run<3, true>("mode 3 + HBM stream (64 KB per CU and round)", st, payload, stream, vecs, cyc, nwg);
   return 0;
 }
