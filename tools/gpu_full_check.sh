@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 4: full GPU suite, the driver's bench command, the default user path, the N = 2 rehearsal and the N = 8 flow rehearsal
+# One GPU call that checks a round: the full GPU suite, the driver's bench command, the default user path (--auto-kv), the N = 2 plan and
+# the N = 8 record flow rehearsed with two ranks on the one card.  Logs: gpurun_out/r4f_*
 set -o pipefail
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -q > gpurun_out/r4f_pytest.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/r4f_pytest.log
