@@ -48,6 +48,8 @@ def describe_status(words) -> str:
             f"({lag} call(s) behind: the peer never reached this call)")
 
 MAX_BYTES = 8 << 20           # largest message taken (256 tokens x 8192 x 2 B = 4 MiB for Qwen2-72B)
+VALIDATION_WAIT_MS = 3000     # bound of a peer wait during the start-up validation (ranks sharing ONE card are time-sliced)
+SERVING_WAIT_MS = 20000       # csrc/allreduce.hip: kDefaultWaitMs
 _lib = hip_ops._lib
 
 
@@ -111,7 +113,13 @@ class CustomAllReduce:
         if not _all_ok(ok, g):
             return self._give_up()
         try:
+            # a peer wait that expires during the validation means "do not use this kernel", not "wait again": a short
+            # bound here (the code object is loaded, every rank is inside the same call), the serving bound afterwards —
+            # 65 validation calls at the serving bound would be twenty minutes of start-up on a box whose peer loads
+            # cannot see each other
+            self.set_wait_limit_ms(VALIDATION_WAIT_MS)
             ok = self._validate()
+            self.set_wait_limit_ms(SERVING_WAIT_MS)
         except Exception as e:  # noqa: BLE001
             logger.warning("custom all-reduce: validation raised on rank %d: %s", self.rank, e)
             ok = False
@@ -151,6 +159,13 @@ class CustomAllReduce:
                                        int((got != want).sum()), int((inplace != want).sum()),
                                        describe_status(self.status_words()))
                     good = good and ok
+                # a wait that gave up anywhere ends the validation HERE, on every rank together (the decision is itself
+                # a collective, so the ranks' backend calls stay aligned): the remaining sizes would only time out again
+                mine = self.status_words()
+                if mine[0] != 0:
+                    logger.warning("custom all-reduce validation on rank %d: %s", self.rank, describe_status(mine))
+                if not _all_ok(mine[0] == 0, self.group):
+                    return False
         # the fused all-reduce + add + RMSNorm launch against the unfused pair (exact sums -> identical inputs
         # to the norm; the row norm itself may differ in the last bit of rstd: compare within 2 ulp)
         for dtype, (m, k) in ((torch.bfloat16, (8 * self.world, 2048)), (torch.float16, (self.world, 3584)),
