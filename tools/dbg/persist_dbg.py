@@ -1,4 +1,6 @@
-"""Debug driver of the persistent decode launch at the bench's B=1 cell: eager and graph steps, status words, step times."""
+"""Debug driver of the persistent decode launch (csrc/decode_persistent.hip) at the bench's B = 1 / 8 cells: graph steps, status
+words, step times, and the phase stamps of layer 1 (flags bit 8) with two weight chunks per wave in flight and with none —
+the table of profiles/r04_persistent_decode.md."""
 import json, os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -37,6 +39,7 @@ def run(eager, batch, layers=None):
 
 NAMES = ["bar A", "norm1", "qkv", "bar B", "attention", "bar C", "combine", "bar D", "o_proj", "bar E", "norm2", "gate_up", "bar F", "down"]
 from minivllm_amd.glue import qwen
+qwen.PERSISTENT = True          # (off by default: MV_PERSISTENT=1)
 for pre in (2, 0xff):
     qwen.PERSISTENT_FLAGS = 0x100 | pre
     for b in (1, 8):
