@@ -235,6 +235,9 @@ size_t mv_decode_layers_persistent_workspace_bytes(int m, int hidden, int n_head
                                                    int block_size, int max_blocks);
 int mv_decode_layers_persistent(const MvPersistLayer *layers_dev, int n_layers, MvPersistArgs *a, void *workspace,
                                 size_t ws_bytes, unsigned *status_dev, int dtype, int flags, void *stream);
+/* sizeof(MvPersistLayer) (which = 0) / sizeof(MvPersistArgs) (which = 1) as this library was built: a binding checks its own
+ * struct declarations against them (host only) */
+size_t mv_persist_struct_bytes(int which);
 
 /* K9 — SiluAndMul: out[r, c] = silu(x[r, c]) * x[r, cols + c].
  * Replaces SiluAndMul.forward (minivllm/models/layers/activation.py:70-96). */

@@ -572,6 +572,8 @@ int device_cus() {
 int mv_paged_decode_plan(int batch, int n_heads, int n_kv_heads, int head_dim, int block_size, int max_blocks, int dtype,
                          int flags, int *g_chunk, int *n_chunks, int *nsplit, int *wide, int *mfma, int *uniform);
 
+extern "C" size_t mv_persist_struct_bytes(int which) { return which == 0 ? sizeof(MvPersistLayer) : sizeof(MvPersistArgs); }
+
 extern "C" size_t mv_decode_layers_persistent_workspace_bytes(int m, int hidden, int n_heads, int n_kv_heads, int head_dim,
                                                               int inter, int block_size, int max_blocks) {
   if (m <= 0) return 256;

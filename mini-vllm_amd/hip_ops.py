@@ -105,6 +105,7 @@ _SIGNATURES = {
     "mv_topc_pick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mv_decode_layers_persistent_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "mv_decode_layers_persistent": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p]),
+    "mv_persist_struct_bytes": (c_size_t, [c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

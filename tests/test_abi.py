@@ -39,6 +39,15 @@ def test_workspace_size_queries_are_host_only():
     assert hip_ops.paged_decode_workspace_bytes(1, 16, 8, 96, 64, 64) == 256         # unsupported D: nothing
 
 
+def test_struct_layouts_of_the_binding_match_the_library():
+    """mv_decode_layers_persistent takes two structs by pointer: the ctypes declarations must have the library's layout."""
+    from minivllm_amd import hip_ops
+
+    assert hip_ops.lib().mv_persist_struct_bytes(1) == ctypes.sizeof(hip_ops.MvPersistArgs)
+    assert hip_ops.lib().mv_persist_struct_bytes(0) == 8 * len(hip_ops.PERSIST_LAYER_FIELDS)   # a row of the int64 layer table
+    assert hip_ops.lib().mv_decode_layers_persistent_workspace_bytes(1, 2048, 16, 8, 128, 6144, 64, 64) > 4096
+
+
 def test_no_cpu_fallback():
     from minivllm_amd import hip_ops
 
