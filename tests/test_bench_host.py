@@ -78,3 +78,56 @@ def test_prefill_flops_formula():
     # 4 H D (Sq Sk - Sq (Sq - 1) / 2); S = 4096, H = 28, D = 128 -> 1.20e11 per sequence and layer
     assert abs(bench.prefill_flops(28, 128, [4096]) / 1.20e11 - 1) < 0.01
     assert bench.prefill_flops(16, 128, [1024] * 16) == 16 * 4 * 16 * 128 * (1024 * 1024 - 1024 * 1023 // 2)
+
+
+def test_run_records_executes_the_n8_plan_in_order(monkeypatch, tmp_path):
+    """The N = 8 run end to end on stand-ins (no GPU): headline engine, then the Qwen2-7B engine construction that the head
+    rule rejects -> a record with the error text (every rank raises the same error, so the ranks stay in step), then ONE
+    Qwen2-72B engine with a KV pool sized from free HBM and max_model_len 4096, capturing only the bucket it replays;
+    engines are exited before the next one is built."""
+    events = []
+
+    class FakeEngine:
+        def __init__(self, model):
+            self.model = model
+            ex = type("Ex", (), {})()
+            ex.kv_cache = type("KV", (), {"shape": (2, 80, 16384, 64, 1, 128), "numel": lambda self: 2 * 80 * 16384 * 64 * 128})()
+            ex.dtype = type("DT", (), {"itemsize": 2})()
+            self.model_runner = type("MR", (), {"inference_executor": ex})()
+
+        def exit(self):
+            events.append(("exit", self.model))
+
+    def fake_build(args, workdir, model=None, max_model_len=None, auto_kv=None):
+        events.append(("build", model, args.gpus, max_model_len, auto_kv, os.environ.get("MV_GRAPH_BATCH_SIZES")))
+        if model == "qwen2-7b" and args.gpus == 8:
+            raise ValueError("total_num_heads (28) must be divisible by tp_size (8)")
+        return FakeEngine(model)
+
+    def fake_decode(engine, args, model, dist, sampling=None, seed=0, probes=True):
+        events.append(("decode", model, args.batch, args.ctx, args.steps))
+        return {"metric": "decode tokens/s", "model": model, "tp": args.gpus, "value": 1.0, "ms_per_step": 1.0,
+                "config": {"workload": model}}, 123.0
+
+    monkeypatch.setattr(bench, "build_engine", fake_build)
+    monkeypatch.setattr(bench, "decode_record", fake_decode)
+    monkeypatch.setattr(bench, "release_all", lambda e: events.append(("release", e.model)))
+    monkeypatch.setattr(bench, "projection_roofline", lambda e, rows: {"rows": rows})
+    monkeypatch.delenv("MV_GRAPH_BATCH_SIZES", raising=False)
+    args = bench.parse(["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    records, tps = bench.run_records(args, str(tmp_path), dist=None)
+    assert [r["model"] for r in records] == ["qwen3-1.7b", "qwen2-7b", "qwen2-72b"] and tps == 123.0
+    assert records[0]["headline"] and records[0]["projection_roofline"] == {"rows": 256}
+    rej = records[1]
+    assert rej["status"] == "rejected, as in reference" and rej["value"] is None and "divisible by tp_size (8)" in rej["error"]
+    big = records[2]
+    pool = big["config"]["kv_pool_per_gpu"]
+    assert pool["blocks"] == 16384 and pool["local_kv_heads"] == 1 and pool["block_bytes"] == 2 * 80 * 64 * 1 * 128 * 2
+    builds = [e for e in events if e[0] == "build"]
+    assert builds[0][1:5] == ("qwen3-1.7b", 8, None, None) and builds[0][5] is None          # the headline captures every bucket
+    assert builds[1][1] == "qwen2-7b"
+    assert builds[2][1:5] == ("qwen2-72b", 8, 4096, True) and builds[2][5] == "256"          # one bucket, HBM-sized pool
+    assert "MV_GRAPH_BATCH_SIZES" not in os.environ
+    # the headline engine is gone before the rejected construction, the last engine at the end
+    order = [e[:2] for e in events if e[0] in ("build", "exit")]
+    assert order == [("build", "qwen3-1.7b"), ("exit", "qwen3-1.7b"), ("build", "qwen2-7b"), ("build", "qwen2-72b"), ("exit", "qwen2-72b")]
