@@ -102,6 +102,53 @@ __device__ __forceinline__ void paged_decode_body(const DecodeParams &p, const i
   const int u_begin = split * ups;
   const int u_end = min(units, u_begin + ups);
 
+  // q fragments: this lane's 16-byte piece of each of the G heads
+  u32x4 qraw[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int gg = g < g_live ? g : 0;
+    const T *qp = (const T *)p.q + (int64_t)b * p.q_stride + (int64_t)(h0 + gg) * D + sub * VEC;
+    qraw[g] = ld16<COH>(qp);
+  }
+  if constexpr (ROPE) {
+    static_assert(!ROPE || elem<Tag>::VEC == 8, "rope fusion: 16-bit dtypes");
+    // rotary factors of this sequence's position for this lane's dims (rope_qk_store_kernel's table lookup)
+    const int64_t pos = p.positions[b];
+    const bool pos_ok = pos >= 0 && pos < p.max_pos;
+    float cs[VEC], sn[VEC];
+    const int i0 = (sub % (LPT / 2)) * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      cs[j] = pos_ok ? p.cos[pos * (D / 2) + i0 + j] : 1.0f;
+      sn[j] = pos_ok ? p.sin[pos * (D / 2) + i0 + j] : 0.0f;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) qraw[g] = norm_rope_row<Tag, D>(qraw[g], (const T *)p.q_norm_w, p.eps, sub, cs, sn);
+    // the workgroup that will read the sequence's last token writes its K / V rows first (one wave; WIDE: its four
+    // lane groups are the four kv heads, else lane group 0 has the workgroup's kv head)
+    int64_t slot = p.slot_mapping ? (int64_t)p.slot_mapping[b] : -1;
+    if (slot >= p.num_blocks * p.block_size) slot = -1;
+    const int u_last = ctx > 0 ? (ctx - 1) / UNIT : -1;
+    if (write && slot >= 0 && u_last >= u_begin && u_last < u_end && wave == 0 && (WIDE || grp == 0)) {
+      const u32x4 kraw = ld16<COH>((const T *)p.k_new + (int64_t)b * p.k_stride + (int64_t)hkv * D + sub * VEC);
+      const u32x4 vraw = ld16<COH>((const T *)p.v_new + (int64_t)b * p.v_stride + (int64_t)hkv * D + sub * VEC);
+      const u32x4 krot = norm_rope_row<Tag, D>(kraw, (const T *)p.k_norm_w, p.eps, sub, cs, sn);
+      *(MV_AS1 u32x4 *)((T *)p.k_cache + (slot * p.n_kv_heads + hkv) * D + sub * VEC) = krot;
+      *(MV_AS1 u32x4 *)((T *)p.v_cache + (slot * p.n_kv_heads + hkv) * D + sub * VEC) = vraw;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows are in L2 before any wave of the workgroup asks
+    }
+    __syncthreads();
+  }
+
+  float m[G], l[G], acc[G][VEC];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    m[g] = NEG_BIG;
+    l[g] = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[g][j] = 0.f;
+  }
+
   const int32_t *table = p.block_tables + (int64_t)b * p.table_stride;
   const int64_t row_stride = (int64_t)p.n_kv_heads * D;  // elements between token rows
   const MV_AS1 T *kbase = (const MV_AS1 T *)p.k_cache + (int64_t)hkv * D + sub * VEC;
@@ -144,87 +191,6 @@ __device__ __forceinline__ void paged_decode_body(const DecodeParams &p, const i
     }
   };
 
-  // a tile at or past the context is skipped whole (wave-uniform)
-  auto live = [&](int u) { return u < u_end && (u * NW + wave) * TILE < ctx; };
-  // ROPE (the small-step form, latency-bound): the first K/V tile is requested BEFORE q is touched — it depends on the block
-  // table only — so that its HBM latency runs beside the q loads, the rotary table lookups and the rotation.  The one row it
-  // cannot hold yet is the step's own token: the wave that will consume that position computes the new K / V row itself
-  // (below), writes it to the cache and puts it into the tile's registers in place of what the early load returned.
-  u32x4 k0[ROPE ? NLOAD : 1], v0[ROPE ? NLOAD : 1];
-  bool valid0[ROPE ? NLOAD : 1];
-  if constexpr (ROPE) {
-    if (live(u_begin)) load_tile(u_begin, k0, v0, valid0);
-  }
-
-  // q fragments: this lane's 16-byte piece of each of the G heads
-  u32x4 qraw[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int gg = g < g_live ? g : 0;
-    const T *qp = (const T *)p.q + (int64_t)b * p.q_stride + (int64_t)(h0 + gg) * D + sub * VEC;
-    qraw[g] = ld16<COH>(qp);
-  }
-  if constexpr (ROPE) {
-    static_assert(!ROPE || elem<Tag>::VEC == 8, "rope fusion: 16-bit dtypes");
-    // rotary factors of this sequence's position for this lane's dims (rope_qk_store_kernel's table lookup)
-    const int64_t pos = p.positions[b];
-    const bool pos_ok = pos >= 0 && pos < p.max_pos;
-    float cs[VEC], sn[VEC];
-    const int i0 = (sub % (LPT / 2)) * VEC;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      cs[j] = pos_ok ? p.cos[pos * (D / 2) + i0 + j] : 1.0f;
-      sn[j] = pos_ok ? p.sin[pos * (D / 2) + i0 + j] : 0.0f;
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) qraw[g] = norm_rope_row<Tag, D>(qraw[g], (const T *)p.q_norm_w, p.eps, sub, cs, sn);
-    // the workgroup that will read the sequence's last token writes its K / V rows first: the wave (and, per-head mapping, the
-    // lane group) that consumes that token's position — it then holds the row it needs (WIDE: the four lane groups are the
-    // four kv heads)
-    int64_t slot = p.slot_mapping ? (int64_t)p.slot_mapping[b] : -1;
-    if (slot >= p.num_blocks * p.block_size) slot = -1;
-    const int u_last = ctx > 0 ? (ctx - 1) / UNIT : -1;
-    const int r_in_unit = ctx > 0 ? (ctx - 1) - u_last * UNIT : 0;
-    const int w_star = r_in_unit / TILE, off_star = r_in_unit % TILE;
-    const int i_star = WIDE ? off_star : off_star / TPL, g_star = WIDE ? 0 : off_star % TPL;
-    bool reload0 = false;
-    if (slot >= 0 && u_last >= u_begin && u_last < u_end && wave == w_star) {
-      // is `slot` the row the block table gives for that position?  (always, in the engine; a caller with other slots gets the
-      // original order: store, then the tile is read again)
-      const int tpos = ctx - 1;
-      const int bi = p.bs_shift >= 0 ? (tpos >> p.bs_shift) : (tpos / p.block_size);
-      const int blk = bi < p.max_blocks ? table[bi] : -1;
-      const bool same = blk >= 0 && blk < p.num_blocks && (int64_t)blk * p.block_size + (tpos - bi * p.block_size) == slot;
-      if (WIDE || grp == g_star) {
-        const u32x4 kraw = ld16<COH>((const T *)p.k_new + (int64_t)b * p.k_stride + (int64_t)hkv * D + sub * VEC);
-        const u32x4 vraw = ld16<COH>((const T *)p.v_new + (int64_t)b * p.v_stride + (int64_t)hkv * D + sub * VEC);
-        const u32x4 krot = norm_rope_row<Tag, D>(kraw, (const T *)p.k_norm_w, p.eps, sub, cs, sn);
-        if (write) {
-          *(MV_AS1 u32x4 *)((T *)p.k_cache + (slot * p.n_kv_heads + hkv) * D + sub * VEC) = krot;
-          *(MV_AS1 u32x4 *)((T *)p.v_cache + (slot * p.n_kv_heads + hkv) * D + sub * VEC) = vraw;
-        }
-        if (same && u_last == u_begin) {
-#pragma unroll
-          for (int i = 0; i < NLOAD; ++i)
-            if (i == i_star) k0[i] = krot, v0[i] = vraw;
-        }
-      }
-      reload0 = !same && u_last == u_begin;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows are in L2 before any wave of the workgroup asks
-    }
-    __syncthreads();
-    if (reload0) load_tile(u_begin, k0, v0, valid0);   // (wave-uniform)
-  }
-
-  float m[G], l[G], acc[G][VEC];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    m[g] = NEG_BIG;
-    l[g] = 0.f;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[g][j] = 0.f;
-  }
-
   auto consume_tile = [&](const u32x4 (&kraw)[NLOAD], const u32x4 (&vraw)[NLOAD], const bool (&valid)[NLOAD]) {
     // scores (log2 domain) + online softmax, per query head
     float pr[G][NLOAD];
@@ -264,15 +230,11 @@ __device__ __forceinline__ void paged_decode_body(const DecodeParams &p, const i
     }
   };
 
+  // a tile at or past the context is skipped whole (wave-uniform)
+  auto live = [&](int u) { return u < u_end && (u * NW + wave) * TILE < ctx; };
   // (round 2: a second register set with the next tile's loads in flight during the arithmetic — 256 VGPRs,
   //  2 waves per SIMD — measured no faster than this loop, 166 vs 165 us: the HBM side is the limit)
   for (int u = u_begin; live(u); ++u) {
-    if constexpr (ROPE) {
-      if (u == u_begin) {          // requested above, before q
-        consume_tile(k0, v0, valid0);
-        continue;
-      }
-    }
     u32x4 kraw[NLOAD], vraw[NLOAD];
     bool valid[NLOAD];
     load_tile(u, kraw, vraw, valid);
