@@ -124,6 +124,33 @@ def test_persistent_launch_is_bit_identical_to_the_launches(tmp_path, monkeypatc
         toks = ta
 
 
+def test_persistent_launch_soak_every_step_compared(tmp_path, monkeypatch):
+    """300 consecutive decode steps (contexts growing across block edges, 3 rows), each run both ways on the same state and
+    compared bit for bit — 300 x 17 grid barriers' worth of fence-free hand-offs with warm caches and whatever arrival skew
+    the chip produces; the status word stays clean."""
+    from minivllm_amd.engine.block_manager import BlockManager
+    from minivllm_amd.glue import qwen
+
+    cfg, model, ex = _executor(tmp_path, QWEN3_17B_3L)
+    bm = BlockManager(cfg.num_kvcache_blocks, 64)
+    seqs = _sequences([60, 1, 125], 4096, 64, bm)
+    monkeypatch.setattr(qwen, "PERSISTENT", False)
+    _, toks = ex.execute_batch(seqs, prefill=True)
+    for step in range(300):
+        for s, t in zip(seqs, toks):
+            s.append_token(int(t))
+            bm.may_append(s)
+        monkeypatch.setattr(qwen, "PERSISTENT", False)
+        la, ta = ex.execute_batch(seqs, prefill=False)
+        la = la.clone()
+        monkeypatch.setattr(qwen, "PERSISTENT", True)
+        lb, tb = ex.execute_batch(seqs, prefill=False)
+        assert torch.equal(la, lb) and ta == tb, f"step {step}"
+        assert model.model.persistent_give_ups() == 0
+        toks = ta
+    assert not model.model._persist.get("declined")
+
+
 def test_persistent_launch_without_prefetch_and_in_f16(tmp_path, monkeypatch):
     """The same bits with no weight chunk in flight across the barriers (flag 0xff: every chunk loaded behind the
     barrier), with one chunk, and in float16."""
